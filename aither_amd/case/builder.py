@@ -1,0 +1,267 @@
+"""Assemble a runnable case: what the reference's main.cpp:100-203 produces
+before its time-step loop (input parsing, nondimensionalisation, grid metrics,
+ghost geometry, connections, wall distance, initial state), as plain arrays in
+the reference's host layout ready to cross the C-ABI.
+"""
+from dataclasses import dataclass, field
+import os
+import numpy as np
+
+from . import fluid as _fluid
+from . import geometry as _geo
+from . import connections as _conn
+from .inputfile import parse_input, InputDeck, Surface, State
+from .. import abi
+
+
+@dataclass
+class Block:
+    geom: "_geo.BlockGeometry"
+    surfaces: list
+    state: np.ndarray          # [nk+2g, nj+2g, ni+2g, n_eq]
+    parent: int = 0
+    global_pos: int = 0
+    rank: int = 0
+    local_pos: int = 0
+
+
+@dataclass
+class Case:
+    deck: InputDeck
+    gas: "_fluid.Gas"
+    blocks: list
+    connections: list
+    total_cells: int
+    n_eq: int = 5
+
+    @property
+    def ng(self):
+        return self.deck.num_ghost_layers()
+
+
+def nondim_state(deck, gas, st):
+    """icState::Nondimensionalize (inputStates.cpp:464-473) and the
+    per-BC variants (:590-599, :674-681, :775-783)."""
+    r_ref, a_ref, t_ref, l_ref = gas.rho_ref, gas.a_ref, gas.t_ref, gas.l_ref
+    out = abi.BcState()
+    kind = st.kind
+    if kind in ("icState", "characteristic", "supersonicInflow", "inlet",
+                "subsonicInflow"):
+        vel = st.get("velocity", [0.0, 0.0, 0.0])
+        for c in range(3):
+            out.velocity[c] = vel[c] / a_ref
+        out.density = st.get("density", 0.0) / r_ref
+        out.pressure = st.get("pressure", 0.0) / (r_ref * a_ref * a_ref)
+        if kind == "inlet":
+            out.is_nonreflecting = int(bool(st.get("nonreflecting", False)))
+            out.length_scale = st.get("lengthScale", 0.0) / l_ref
+    elif kind == "stagnationInlet":
+        d = st.get("direction", [0.0, 0.0, 0.0])
+        for c in range(3):
+            out.direction[c] = d[c]       # Normalize() result is discarded (:594)
+        out.stagnation_pressure = st.get("p0") / (r_ref * a_ref * a_ref)
+        out.stagnation_temperature = st.get("t0") / t_ref
+    elif kind in ("pressureOutlet", "subsonicOutflow"):
+        out.pressure = st.get("pressure") / (r_ref * a_ref * a_ref)
+        out.is_nonreflecting = int(bool(st.get("nonreflecting", False)))
+        out.length_scale = st.get("lengthScale", 0.0) / l_ref
+    elif kind == "viscousWall":
+        vel = st.get("velocity", [0.0, 0.0, 0.0])
+        for c in range(3):
+            out.velocity[c] = vel[c] / a_ref
+        if st.get("temperature") is not None:
+            out.is_isothermal = 1
+            out.wall_temperature = st.get("temperature") / t_ref
+        if st.get("heatFlux") is not None:
+            out.is_heat_flux = 1
+            out.wall_heat_flux = st.get("heatFlux") / ((a_ref / l_ref) ** 3.0)
+        if st.get("wallTreatment", "lowRe") != "lowRe":
+            raise NotImplementedError("wall-law boundaries are out of scope")
+    elif kind == "periodic":
+        pass
+    else:
+        raise NotImplementedError(f"boundary state {kind}")
+    return out
+
+
+def initial_primitive(deck, gas, block):
+    """primitive::NondimensionalInitialize (primitive.cpp:40-64)."""
+    ic = deck.ic_for_block(block)
+    if ic.get("file") is not None:
+        raise NotImplementedError("cloud-file initial conditions")
+    s = nondim_state(deck, gas, State("icState", ic.params))
+    return np.array([1.0 * s.density, s.velocity[0], s.velocity[1],
+                     s.velocity[2], s.pressure])
+
+
+def _wall_distance(blocks):
+    """main.cpp:191-203: nearest viscous-wall face centre (k-d tree), then the
+    ghost-cell rule of procBlock::CalcWallDistance (procBlock.cpp:6030-6107)."""
+    from scipy.spatial import cKDTree
+    pts = []
+    for b in blocks:
+        g = b.geom
+        for s in b.surfaces:
+            if s.bc_type != "viscousWall":
+                continue
+            f = s.dir3()
+            rng = {"i": s.rng("i"), "j": s.rng("j"), "k": s.rng("k")}
+            pts.append(g.fcen[f].v(rng["i"], rng["j"], rng["k"]).reshape(-1, 3))
+    if not pts:
+        return
+    tree = cKDTree(np.concatenate(pts))
+    for b in blocks:
+        g = b.geom
+        ni, nj, nk, ng = g.ni, g.nj, g.nk, g.ng
+        cen = g.center.phys().reshape(-1, 3)
+        dist, _ = tree.query(cen)
+        wd = g.wall_dist
+        wd.phys()[..., 0] = dist.reshape(nk, nj, ni)
+        n = {"i": ni, "j": nj, "k": nk}
+        for s in b.surfaces:
+            d = s.dir3()
+            st = s.surface_type()
+            r = {q: s.rng(q) for q in "ijk"}
+            for layer in range(1, ng + 1):
+                if st % 2 == 1:
+                    gidx = -layer
+                    src = (layer - 1) if s.bc_type == "viscousWall" else 0
+                else:
+                    gidx = n[d] + layer - 1
+                    src = (n[d] - layer) if s.bc_type == "viscousWall" \
+                        else n[d] - 1
+                sign = -1.0 if s.bc_type == "viscousWall" else 1.0
+                rg, rs = dict(r), dict(r)
+                rg[d] = (gidx, gidx + 1)
+                rs[d] = (src, src + 1)
+                wd.v(rg["i"], rg["j"], rg["k"])[...] = \
+                    sign * wd.v(rs["i"], rs["j"], rs["k"])
+
+
+def build_case(inp_path, grid_dir=None, deck=None, coords=None, ranks=None):
+    """Build a Case from an .inp file (and its .xyz grid).  `deck`/`coords`
+    may be given directly for synthetic cases."""
+    if deck is None:
+        deck = parse_input(inp_path)
+    deck.validate()
+    fluid_name = deck.fluids[0] if deck.fluids else "air"
+    gas = _fluid.make_gas(fluid_name, deck.t_ref, deck.rho_ref, deck.l_ref)
+    if coords is None:
+        base = grid_dir or os.path.dirname(os.path.abspath(inp_path))
+        coords = _geo.read_plot3d(os.path.join(base, deck.grid_name + ".xyz"),
+                                  deck.l_ref)
+    if len(coords) != len(deck.bcs):
+        raise ValueError("number of grid blocks and BC blocks differ")
+    ng = deck.num_ghost_layers()
+    nblk = len(coords)
+    ranks = ranks or [0] * nblk
+    local_pos = []
+    counts = {}
+    for r in ranks:
+        local_pos.append(counts.get(r, 0))
+        counts[r] = counts.get(r, 0) + 1
+    blocks = []
+    total = 0
+    for b, x in enumerate(coords):
+        g = _geo.BlockGeometry(x, ng)
+        g.assign_ghost_geom(deck.bcs[b])
+        prim = initial_primitive(deck, gas, b)
+        st = np.zeros((g.nk + 2 * ng, g.nj + 2 * ng, g.ni + 2 * ng, 5))
+        st[ng:ng + g.nk, ng:ng + g.nj, ng:ng + g.ni, :] = prim
+        blocks.append(Block(g, deck.bcs[b], st, b, b, ranks[b], local_pos[b]))
+        total += g.ni * g.nj * g.nk
+    conns = _conn.find_connections(deck.bcs, coords, deck, ranks, local_pos)
+    geoms = [b.geom for b in blocks]
+    for c in conns:
+        if c.is_interblock:
+            _conn.swap_geom(c, geoms)
+    for b in blocks:
+        b.geom.assign_ghost_geom_edge()
+        b.geom.calc_cell_widths()
+    if deck.is_viscous():
+        _wall_distance(blocks)
+        # SwapWallDist (gridLevel.cpp:261-285)
+        for c in conns:
+            _swap_cell_field(c, blocks, lambda blk: blk.geom.wall_dist.a, ng)
+    return Case(deck, gas, blocks, conns, total)
+
+
+def _swap_cell_field(conn, blocks, getter, ng):
+    b0, b1 = blocks[conn.block[0]], blocks[conn.block[1]]
+    a0, a1 = getter(b0), getter(b1)
+    nc = a0.shape[-1]
+    f0, f1 = a0.reshape(-1, nc), a1.reshape(-1, nc)
+    dst0, src1, _ = _conn.insert_maps(conn, True, ng, b0.geom.n, b1.geom.n)
+    dst1, src0, _ = _conn.insert_maps(conn, False, ng, b1.geom.n, b0.geom.n)
+    s1 = f1[src1].copy()
+    s0 = f0[src0].copy()
+    f0[dst0] = s1
+    f1[dst1] = s0
+
+
+# ---------------------------------------------------------------------------
+def config_struct(case):
+    d, g = case.deck, case.gas
+    cfg = abi.Config()
+    cfg.n_eq = 5
+    cfg.n_ghost = d.num_ghost_layers()
+    if d.face_reconstruction == "constant":
+        cfg.recon = abi.RECON["constant"]
+    elif d.using_muscl():
+        cfg.recon = abi.RECON["muscl"]
+    else:
+        cfg.recon = abi.RECON[d.face_reconstruction]
+    cfg.limiter = abi.LIMITER[d.limiter]
+    cfg.inviscid_flux = abi.FLUX[d.inviscid_flux]
+    cfg.is_viscous = int(d.is_viscous())
+    cfg.time_integration = abi.TIME[d.time_integration]
+    cfg.matrix_solver = abi.SOLVER[d.matrix_solver]
+    cfg.matrix_sweeps = d.matrix_sweeps
+    cfg.nonlinear_iterations = d.nonlinear_iterations
+    cfg.kappa = d.kappa
+    cfg.theta, cfg.zeta = d.theta, d.zeta
+    cfg.matrix_relaxation = d.matrix_relaxation
+    cfg.dual_time_cfl = d.dual_time_cfl
+    cfg.dt_nondim = d.dt * g.a_ref / g.l_ref if d.dt > 0.0 else -1.0
+    cfg.viscous_cfl_coeff = d.viscous_cfl_coefficient()
+    for name, _ in abi.Gas._fields_:
+        setattr(cfg.gas, name, getattr(g, name))
+    return cfg
+
+
+def surface_structs(case, block):
+    blk = case.blocks[block]
+    arr = (abi.BcSurface * len(blk.surfaces))()
+    for n, s in enumerate(blk.surfaces):
+        a = arr[n]
+        a.bc_type = abi.BC[s.bc_type]
+        a.imin, a.imax, a.jmin, a.jmax = s.imin, s.imax, s.jmin, s.jmax
+        a.kmin, a.kmax, a.tag = s.kmin, s.kmax, s.tag
+        if s.bc_type in ("characteristic", "supersonicInflow", "inlet",
+                         "stagnationInlet", "pressureOutlet", "viscousWall"):
+            try:
+                st = case.deck.bc_data(s.tag)
+            except KeyError:
+                if s.bc_type == "viscousWall":
+                    st = State("viscousWall", {})
+                else:
+                    raise
+            a.state = nondim_state(case.deck, case.gas, st)
+    return arr
+
+
+def connection_struct(conn):
+    c = abi.Connection()
+    for side in range(2):
+        c.rank[side] = conn.rank[side]
+        c.block[side] = conn.block[side]
+        c.local_block[side] = conn.local_block[side]
+        c.boundary[side] = conn.boundary[side]
+        c.d1_start[side], c.d1_end[side] = conn.d1s[side], conn.d1e[side]
+        c.d2_start[side], c.d2_end[side] = conn.d2s[side], conn.d2e[side]
+        c.const_surf[side] = conn.const_surf[side]
+    for n in range(8):
+        c.patch_border[n] = int(conn.border[n])
+    c.orientation = conn.orientation
+    c.is_interblock = int(conn.is_interblock)
+    return c

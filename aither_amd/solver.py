@@ -1,0 +1,164 @@
+"""Host-side mirror of the reference's time-step loop around the C-ABI.
+
+`Solver` plays the role of main.cpp:231-302 + logFileManager: it owns one
+library context, uploads a Case (aither_amd.case.builder.Case), and calls
+store_time_n / iterate exactly where the reference calls
+mgSolution::StoreOldSolution (main.cpp:239) and mgSolution::Iterate
+(main.cpp:249).  Residual normalisation follows PrintResiduals
+(src/output.cpp:1028-1087).  PyTorch is not involved here; the same class
+drives the product library ("agx_") and, in tests only, the CPU oracle
+("ora_").
+"""
+import ctypes as C
+import math
+import numpy as np
+
+from . import abi
+from .case import builder as _b
+
+EPS = 1.0e-30  # macros.hpp.in:20
+
+
+class Solver:
+    def __init__(self, api, case, device=0, rank=0, stream=None):
+        self.api, self.case, self.rank = api, case, rank
+        self.ctx = C.c_void_p()
+        api.check(api.ctx_create(device, rank, C.byref(self.ctx)), "ctx_create")
+        if stream is not None:
+            api.check(api.ctx_set_stream(self.ctx, C.c_void_p(stream)),
+                      "ctx_set_stream")
+        self.cfg = _b.config_struct(case)
+        api.check(api.config_set(self.ctx, C.byref(self.cfg)), "config_set")
+        self._keep = []
+        self.block_ids = {}
+        for gb, blk in enumerate(case.blocks):
+            if blk.rank != rank:
+                continue
+            g = blk.geom
+            bg = abi.BlockGeom()
+            bg.ni, bg.nj, bg.nk, bg.ng = g.ni, g.nj, g.nk, g.ng
+            bg.parent_block, bg.global_pos = blk.parent, blk.global_pos
+            arrs = dict(farea_i=g.farea["i"].a, farea_j=g.farea["j"].a,
+                        farea_k=g.farea["k"].a, vol=g.vol.a, center=g.center.a,
+                        width_i=g.width["i"].a, width_j=g.width["j"].a,
+                        width_k=g.width["k"].a, wall_dist=g.wall_dist.a)
+            for name, a in arrs.items():
+                a = np.ascontiguousarray(a, dtype=np.float64)
+                self._keep.append(a)
+                setattr(bg, name, a.ctypes.data_as(abi.c_dp))
+            bid = C.c_int(-1)
+            api.check(api.block_create(self.ctx, C.byref(bg), C.byref(bid)),
+                      "block_create")
+            self.block_ids[gb] = bid.value
+            surfs = _b.surface_structs(case, gb)
+            api.check(api.block_set_bcs(self.ctx, bid.value, len(surfs), surfs),
+                      "block_set_bcs")
+        self.conn_ids = []
+        for conn in case.connections:
+            if rank not in conn.rank:
+                self.conn_ids.append(-1)
+                continue
+            cs = _b.connection_struct(conn)
+            for side in range(2):
+                if conn.rank[side] == rank:
+                    cs.local_block[side] = self.block_ids[conn.block[side]]
+            cid = C.c_int(-1)
+            api.check(api.conn_create(self.ctx, C.byref(cs), C.byref(cid)),
+                      "conn_create")
+            self.conn_ids.append(cid.value)
+        api.check(api.setup_finalize(self.ctx), "setup_finalize")
+        for gb, bid in self.block_ids.items():
+            self.upload("state", gb, case.blocks[gb].state)
+        self.l2_first = None
+        self.history = []
+
+    # ------------------------------------------------------------------
+    def close(self):
+        if self.ctx:
+            self.api.ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _shape(self, field, gb):
+        g = self.case.blocks[gb].geom
+        ng = g.ng
+        n_eq = self.cfg.n_eq
+        ghost = field in ("state", "update", "temperature", "viscosity")
+        comps = n_eq if field in ("state", "residual", "cons_n", "update",
+                                  "cons_nm1") else 1
+        pad = 2 * ng if ghost else 0
+        return (g.nk + pad, g.nj + pad, g.ni + pad, comps)
+
+    def upload(self, field, gb, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        assert a.shape == self._shape(field, gb), (a.shape, self._shape(field, gb))
+        if field == "state":
+            rc = self.api.state_upload(self.ctx, self.block_ids[gb],
+                                       a.ctypes.data_as(abi.c_dp))
+        else:
+            rc = self.api.field_upload(self.ctx, self.block_ids[gb],
+                                       abi.FIELD[field],
+                                       a.ctypes.data_as(abi.c_dp))
+        self.api.check(rc, "upload")
+
+    def download(self, field, gb):
+        out = np.empty(self._shape(field, gb))
+        self.api.check(self.api.field_download(
+            self.ctx, self.block_ids[gb], abi.FIELD[field],
+            out.ctypes.data_as(abi.c_dp)), "field_download")
+        return out
+
+    # ------------------------------------------------------------------
+    def store_time_n(self, nn):
+        d = self.case.deck
+        if d.need_to_store_time_n():
+            also = int(d.is_multilevel_in_time() and nn == 0)
+            self.api.check(self.api.store_time_n(self.ctx, also), "store_time_n")
+
+    def iterate(self, mm, cfl):
+        n_eq = self.cfg.n_eq
+        l2 = np.zeros(n_eq)
+        linf = abi.Linf()
+        mres = C.c_double(0.0)
+        self.api.check(self.api.iterate(
+            self.ctx, mm, cfl, l2.ctypes.data_as(abi.c_dp), C.byref(linf),
+            C.byref(mres)), "iterate")
+        return l2, linf, mres.value
+
+    def normalized(self, l2sq, nn, mm):
+        """PrintResiduals (output.cpp:1028-1087) for the single-species case."""
+        l2 = np.sqrt(l2sq)                 # residual::SquareRoot (main.cpp:268)
+        if nn == 0 and mm == 0:
+            self.l2_first = l2.copy()
+        elif nn < 5 and mm == 0:
+            if l2[0] > self.l2_first[0]:
+                self.l2_first[0] = l2[0]
+            self.l2_first[1:] = np.maximum(self.l2_first[1:], l2[1:])
+        return (l2 + EPS) / (self.l2_first + EPS)
+
+    def step(self, nn):
+        d = self.case.deck
+        cfl = d.cfl(nn)
+        self.store_time_n(nn)
+        out = None
+        for mm in range(d.nonlinear_iterations):
+            l2, linf, mres = self.iterate(mm, cfl)
+            total = self.case.total_cells
+            mres = math.sqrt(mres / (total * self.cfg.n_eq))   # main.cpp:271
+            out = dict(nn=nn, mm=mm, l2=np.sqrt(l2),
+                       norm=self.normalized(l2, nn, mm),
+                       linf=(linf.linf, linf.block, linf.i, linf.j, linf.k,
+                             linf.eqn), matrix=mres)
+            self.history.append(out)
+        return out
+
+    def run(self, iterations):
+        out = None
+        for nn in range(iterations):
+            out = self.step(nn)
+        return out

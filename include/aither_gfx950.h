@@ -1,0 +1,253 @@
+/* aither_gfx950.h -- C-ABI of libaither_gfx950.so
+ *
+ * MI355X (gfx950) implementation of AITHER's per-iteration hot path:
+ * ghost-cell fill, face reconstruction, inviscid/viscous fluxes, time step,
+ * explicit update and the LU-SGS / DPLUR implicit sweeps.
+ *
+ * The library stands behind the calls that the reference's
+ *   mgSolution::Iterate            (src/mgSolution.cpp:246-269)
+ * makes on its finest gridLevel, plus the three data-movement points around
+ * it (setup after main.cpp:163-203, StoreOldSolution main.cpp:239, and
+ * GetFinestGridLevel main.cpp:282).  All arrays crossing this boundary use the
+ * reference's own host layout (multiArray3d, include/multiArray3d.hpp:104-113):
+ * AoS, block-size doubles per cell, i fastest, ghost-inclusive dimensions
+ * (n + 2*ng).  The library owns device-resident SoA copies and never aliases
+ * host memory.
+ *
+ * Error convention: every entry point returns 0 on success, non-zero on
+ * failure; agx_last_error() returns a message (the reference prints to cerr
+ * and calls exit(EXIT_FAILURE); the adapter in INTEGRATION.md keeps that).
+ * Not thread-safe: one context per process per device (the reference is
+ * single-threaded per MPI rank).
+ */
+#ifndef AITHER_GFX950_H
+#define AITHER_GFX950_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enumerations (resolved once from the reference's std::string input
+ *      options, include/input.hpp:48-291) -------------------------------- */
+enum { AGX_RECON_CONSTANT = 0, AGX_RECON_MUSCL = 1, AGX_RECON_WENO = 2,
+       AGX_RECON_WENOZ = 3 };                 /* input.cpp:276-303 */
+enum { AGX_LIMITER_NONE = 0, AGX_LIMITER_VANALBADA = 1,
+       AGX_LIMITER_MINMOD = 2 };              /* limiter.cpp:24-54 */
+enum { AGX_FLUX_ROE = 0, AGX_FLUX_AUSM = 1 }; /* inviscidFlux.hpp:484-507 */
+enum { AGX_TIME_EXPLICIT_EULER = 0, AGX_TIME_RK4 = 1,
+       AGX_TIME_IMPLICIT_EULER = 2, AGX_TIME_CRANK_NICHOLSON = 3,
+       AGX_TIME_BDF2 = 4 };                   /* input.cpp:259-275 */
+enum { AGX_SOLVER_LUSGS = 0, AGX_SOLVER_DPLUR = 1 }; /* input.cpp:843-858 */
+
+/* boundary condition types, ghostStates.cpp:62-689 */
+enum { AGX_BC_SLIPWALL = 0, AGX_BC_VISCOUSWALL = 1, AGX_BC_CHARACTERISTIC = 2,
+       AGX_BC_INLET = 3, AGX_BC_SUPERSONIC_INFLOW = 4,
+       AGX_BC_SUPERSONIC_OUTFLOW = 5, AGX_BC_STAGNATION_INLET = 6,
+       AGX_BC_PRESSURE_OUTLET = 7, AGX_BC_INTERBLOCK = 8,
+       AGX_BC_PERIODIC = 9 };
+
+/* fields that can be downloaded (procBlock members, include/procBlock.hpp:60-110) */
+enum { AGX_FIELD_STATE = 0,      /* state_      nEq, with ghosts           */
+       AGX_FIELD_RESIDUAL = 1,   /* residual_   nEq, no ghosts             */
+       AGX_FIELD_DT = 2,         /* dt_         1,   no ghosts             */
+       AGX_FIELD_SPEC_RADIUS = 3,/* specRadius_ 1,   no ghosts (flow part) */
+       AGX_FIELD_CONS_N = 4,     /* consVarsN_  nEq, no ghosts             */
+       AGX_FIELD_UPDATE = 5,     /* linearSolver x_ nEq, with ghosts       */
+       AGX_FIELD_DIAGONAL = 6,   /* linearSolver a_ (scalar) 1, no ghosts  */
+       AGX_FIELD_TEMPERATURE = 7,/* temperature_ 1,  with ghosts           */
+       AGX_FIELD_VISCOSITY = 8,  /* viscosity_  1,   with ghosts           */
+       AGX_FIELD_CONS_NM1 = 9    /* consVarsNm1_ nEq, no ghosts            */
+};
+
+/* what a halo exchange carries (gridLevel.cpp:299-313, utility.cpp:400-423) */
+enum { AGX_HALO_STATE = 0, AGX_HALO_UPDATE = 1 };
+
+/* ---- plain-old-data descriptors --------------------------------------- */
+
+/* single-species calorically-perfect ideal gas + Sutherland transport.
+ * Values are the already-nondimensional ones the reference holds after
+ * input::NondimensionalizeFluid (fluid.cpp:83-97, eos.cpp:26-36,
+ * thermodynamic.cpp:27-41, transport.cpp:31-69). */
+typedef struct agx_gas {
+  double gas_constant;   /* idealGas::gasConst_[0] (nondimensional R)      */
+  double n;              /* fluid::N(): cv = n R, cp = (n+1) R             */
+  double heat_of_formation; /* caloricallyPerfect::hf_[0] (nondimensional) */
+  double visc_c1, visc_s;   /* Sutherland viscosity C1 [kg/(m s K^.5)], S [K] */
+  double cond_c1, cond_s;   /* Sutherland conductivity C1, S               */
+  double t_ref;          /* referenceTemperature [K]                       */
+  double rho_ref;        /* referenceDensity [kg/m^3]                      */
+  double l_ref;          /* referenceLength [m]                            */
+  double a_ref;          /* reference speed of sound [m/s] (input.cpp:608-613) */
+} agx_gas;
+
+/* solver configuration; one per context */
+typedef struct agx_config {
+  int32_t n_eq;              /* 5 (single species, no turbulence)          */
+  int32_t n_ghost;           /* input::NumberGhostLayers (input.cpp:1127)  */
+  int32_t recon;             /* AGX_RECON_*                                */
+  int32_t limiter;           /* AGX_LIMITER_*                              */
+  int32_t inviscid_flux;     /* AGX_FLUX_*                                 */
+  int32_t is_viscous;        /* input::IsViscous                           */
+  int32_t time_integration;  /* AGX_TIME_*                                 */
+  int32_t matrix_solver;     /* AGX_SOLVER_*                               */
+  int32_t matrix_sweeps;     /* input::MatrixSweeps                        */
+  int32_t nonlinear_iterations; /* input::NonlinearIterations              */
+  double kappa;              /* MUSCL kappa (input.cpp:277-292)            */
+  double theta, zeta;        /* Beam-Warming (input.cpp:261-270)           */
+  double matrix_relaxation;  /* input::MatrixRelaxation                    */
+  double dual_time_cfl;      /* input::DualTimeCFL, <= 0: off              */
+  double dt_nondim;          /* Dt * aRef / lRef (procBlock.cpp:808); <= 0:
+                                local time stepping from CFL               */
+  double viscous_cfl_coeff;  /* input::ViscousCFLCoefficient (input.cpp:1110) */
+  agx_gas gas;
+} agx_config;
+
+/* geometry of one block, host AoS arrays with ghosts (procBlock.hpp:65-90).
+ * Face-area arrays hold unitVec3dMag = {nx, ny, nz, |A|} per face
+ * (vector3d.hpp:125-190).  Dimensions with G = 2*ng:
+ *   farea_i: (ni+1+G, nj+G,   nk+G)   x 4
+ *   farea_j: (ni+G,   nj+1+G, nk+G)   x 4
+ *   farea_k: (ni+G,   nj+G,   nk+1+G) x 4
+ *   vol, width_i/j/k, wall_dist: (ni+G, nj+G, nk+G) x 1
+ *   center:  (ni+G, nj+G, nk+G) x 3                                        */
+typedef struct agx_block_geom {
+  int32_t ni, nj, nk;        /* physical cells                             */
+  int32_t ng;                /* ghost layers                               */
+  int32_t parent_block;      /* procBlock::ParentBlock (for L-inf report)  */
+  int32_t global_pos;        /* procBlock::GlobalPos                       */
+  const double *farea_i, *farea_j, *farea_k;
+  const double *vol;
+  const double *center;
+  const double *width_i, *width_j, *width_k;   /* cellWidthI/J/K_          */
+  const double *wall_dist;   /* may be NULL for inviscid                   */
+} agx_block_geom;
+
+/* boundary-state data for one surface: the union of the fields the
+ * reference's inputState subclasses hold (include/inputStates.hpp:112-420),
+ * already nondimensional. */
+typedef struct agx_bc_state {
+  double pressure, density;
+  double velocity[3];
+  double stagnation_pressure, stagnation_temperature;
+  double direction[3];
+  double wall_temperature;   /* viscousWall isothermal                     */
+  double wall_heat_flux;     /* viscousWall constant heat flux             */
+  double length_scale;       /* nonreflecting inlet / outlet               */
+  int32_t is_isothermal, is_heat_flux, is_nonreflecting, pad_;
+} agx_bc_state;
+
+/* one boundarySurface (boundaryConditions.hpp:55-150): index ranges are the
+ * reference's node-style ranges exactly as read from the .inp file. */
+typedef struct agx_bc_surface {
+  int32_t bc_type;           /* AGX_BC_*                                   */
+  int32_t imin, imax, jmin, jmax, kmin, kmax;
+  int32_t tag;
+  agx_bc_state state;
+} agx_bc_surface;
+
+/* POD mirror of class connection (boundaryConditions.hpp:371-433) */
+typedef struct agx_connection {
+  int32_t rank[2];
+  int32_t block[2];          /* global block ids                           */
+  int32_t local_block[2];    /* ids returned by agx_block_create on that rank */
+  int32_t boundary[2];       /* surface type 1..6                          */
+  int32_t d1_start[2], d1_end[2], d2_start[2], d2_end[2];
+  int32_t const_surf[2];
+  int32_t patch_border[8];
+  int32_t orientation;       /* 1..8 (boundaryConditions.cpp:653-727)      */
+  int32_t is_interblock;     /* 0 for periodic                             */
+} agx_connection;
+
+/* L-infinity residual record, class resid (include/resid.hpp) */
+typedef struct agx_linf {
+  double linf;
+  int32_t block, i, j, k, eqn;   /* eqn is 1-based (procBlock.cpp:864)     */
+  int32_t pad_;
+} agx_linf;
+
+typedef struct agx_ctx agx_ctx;
+
+/* ---- context ----------------------------------------------------------- */
+const char *agx_last_error(void);
+const char *agx_version(void);
+/* rank: this process's rank in the job (matches agx_connection.rank[]) */
+int agx_ctx_create(int device, int rank, agx_ctx **out);
+void agx_ctx_destroy(agx_ctx *ctx);
+/* run all library work on this hipStream_t (NULL = default stream) */
+int agx_ctx_set_stream(agx_ctx *ctx, void *hip_stream);
+int agx_config_set(agx_ctx *ctx, const agx_config *cfg);
+
+/* ---- setup: after SendFinestGridLevel / AuxillaryAndWidths / SwapWallDist
+ *      (main.cpp:163-203) ------------------------------------------------ */
+int agx_block_create(agx_ctx *ctx, const agx_block_geom *geom, int *block_id);
+int agx_block_set_bcs(agx_ctx *ctx, int block_id, int n_surfaces,
+                      const agx_bc_surface *surfaces);
+int agx_conn_create(agx_ctx *ctx, const agx_connection *conn, int *conn_id);
+/* finish setup: build index maps, hyperplane order, allocate work arrays */
+int agx_setup_finalize(agx_ctx *ctx);
+
+/* ---- state movement ---------------------------------------------------- */
+/* replaces gridLevel ctor state init / ReadRestart (gridLevel.cpp:55,63-65) */
+int agx_state_upload(agx_ctx *ctx, int block_id, const double *state_aos);
+/* replaces the pack in GetFinestGridLevel (procBlock.cpp:4491-4660) */
+int agx_field_download(agx_ctx *ctx, int block_id, int field, double *out_aos);
+int agx_field_upload(agx_ctx *ctx, int block_id, int field, const double *in_aos);
+
+/* ---- per time step: mgSolution::StoreOldSolution (mgSolution.cpp:103-114):
+ *      consVarsN_ <- ConsVars(state_), and consVarsNm1_ <- consVarsN_ when
+ *      also_nm1 != 0 (first bdf2 step) ----------------------------------- */
+int agx_store_time_n(agx_ctx *ctx, int also_nm1);
+
+/* ---- per nonlinear iteration: mgSolution::Iterate (mgSolution.cpp:246-269).
+ *  mm   -- nonlinear iteration index (RK stage for rk4)
+ *  cfl  -- input::CFL() after input::CalcCFL(nn) (input.cpp:637-639)
+ *  l2   -- n_eq doubles, ACCUMULATED into (sum of residual^2, procBlock.cpp:858)
+ *  linf -- updated only when a larger signed residual is found (:863-866)
+ *  matrix_resid -- returns sum(matrixResid^2)/count (mgSolution.cpp:198-206)
+ * Valid only when every connection has both sides on this rank; otherwise
+ * drive the phases below and exchange halos between them. */
+int agx_iterate(agx_ctx *ctx, int mm, double cfl, double *l2, agx_linf *linf,
+                double *matrix_resid);
+
+/* ---- phases of one iteration, for multi-process runs --------------------
+ * Order (explicit):  bc_faces, [halo STATE], bc_edges, residual, explicit_update
+ * Order (implicit):  bc_faces, [halo STATE], bc_edges, residual, implicit_begin,
+ *                    sweeps x { [halo UPDATE], relax_forward, [halo UPDATE],
+ *                    relax_backward }   (LU-SGS, linearSolver.cpp:430-470)
+ *                    or sweeps x { [halo UPDATE], relax_forward } (DPLUR :509-535)
+ *                    [halo UPDATE], matrix_residual, implicit_update          */
+int agx_phase_bc_faces(agx_ctx *ctx);          /* AssignInviscidGhostCells  procBlock.cpp:2449 */
+int agx_phase_bc_edges(agx_ctx *ctx);          /* AssignInviscidGhostCellsEdge procBlock.cpp:2565 */
+int agx_phase_residual(agx_ctx *ctx, double cfl); /* CalcResidualNoSource :6111 + CalcBlockTimeStep :798 */
+int agx_phase_explicit_update(agx_ctx *ctx, int mm, double *l2, agx_linf *linf); /* UpdateBlock :826 */
+int agx_phase_implicit_begin(agx_ctx *ctx);    /* InvertDiagonal + InitializeMatrixUpdate mgSolution.cpp:225-229 */
+int agx_phase_relax_forward(agx_ctx *ctx, int sweep);  /* LUSGS_Forward :341 / DPLUR :473 */
+int agx_phase_relax_backward(agx_ctx *ctx, int sweep); /* LUSGS_Backward :385 */
+int agx_phase_matrix_residual(agx_ctx *ctx, double *matrix_resid); /* linearSolver::Residual :92 */
+int agx_phase_implicit_update(agx_ctx *ctx, int mm, double *l2, agx_linf *linf); /* UpdateBlocks gridLevel.cpp:418 */
+
+/* halo exchange (multiArray3d.hpp:790-873 SwapSliceLocal / SwapSliceParallel).
+ * local: both sides on this rank. */
+int agx_halo_swap_local(agx_ctx *ctx, int what);
+/* remote: number of doubles in the packed slab of connection conn_id */
+int64_t agx_halo_count(agx_ctx *ctx, int conn_id, int what);
+/* pack this rank's side of the connection into dev_buf (device pointer) */
+int agx_halo_pack(agx_ctx *ctx, int conn_id, int what, double *dev_buf);
+/* unpack the partner's slab from dev_buf into this rank's ghost cells */
+int agx_halo_unpack(agx_ctx *ctx, int conn_id, int what, const double *dev_buf);
+
+/* ---- measurement helpers ----------------------------------------------- */
+/* average duration [ms] of the named kernel group since the last reset,
+ * measured with hipEvents on the library's stream; group: 0 = residual,
+ * 1 = update, 2 = bc, 3 = sweep */
+int agx_timing_enable(agx_ctx *ctx, int on);
+int agx_timing_get(agx_ctx *ctx, int group, double *avg_ms, int64_t *launches);
+int agx_timing_reset(agx_ctx *ctx);
+int agx_sync(agx_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AITHER_GFX950_H */
