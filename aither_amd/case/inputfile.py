@@ -176,7 +176,9 @@ class InputDeck:
     def bc_data(self, tag):
         # input::BCData (input.cpp:1175-1187)
         for st in self.bc_states:
-            if st.get("tag") == tag or st.get("endTag") == tag:
+            # periodic states carry startTag (= Tag()) and endTag
+            if st.get("tag", st.get("startTag")) == tag or \
+                    st.get("endTag") == tag:
                 return st
         raise KeyError(f"no boundaryStates entry for tag {tag}")
 

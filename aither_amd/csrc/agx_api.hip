@@ -1,0 +1,879 @@
+// agx_api.hip -- C-ABI of libaither_gfx950.so (include/aither_gfx950.h).
+//
+// Host side of the library: owns device-resident SoA mirrors of every block,
+// converts the reference's AoS host arrays at upload/download, precomputes the
+// halo index maps and launches the kernels of agx_kernels.hpp in the order of
+// mgSolution::Iterate (src/mgSolution.cpp:246-269).  There is no CPU compute
+// path here: every entry point fails loudly if HIP is unavailable.
+#include "agx_kernels.hpp"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include <algorithm>
+
+using namespace agx;
+
+static char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+#define HIPCHK(call)                                                       \
+  do {                                                                     \
+    hipError_t e_ = (call);                                                \
+    if (e_ != hipSuccess)                                                  \
+      return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+                  __FILE__, __LINE__);                                     \
+  } while (0)
+
+namespace {
+
+struct Block {
+  BlockDev d;
+  int global_pos = 0;
+  std::vector<double*> allocs;
+  agx_bc_surface* surf_dev = nullptr;
+  std::vector<agx_bc_surface> surf_host;
+};
+
+struct ConnSide {          // what side s receives / sends
+  long n = 0;              // cells inserted into side s
+  long* dst = nullptr;     // device: ghost cells of side s (this rank's block)
+  long* src = nullptr;     // device: partner cells that fill them
+};
+struct Conn {
+  agx_connection c;
+  ConnSide side[2];
+  // for remote connections: cells of MY block that the partner's ghosts read
+  long n_send = 0;
+  long* send_src = nullptr;
+};
+
+enum { G_RESID = 0, G_UPDATE = 1, G_BC = 2, G_SWEEP = 3, G_NGROUP = 4 };
+
+}  // namespace
+
+struct agx_ctx {
+  int device = 0, rank = 0;
+  hipStream_t stream = nullptr;
+  bool have_cfg = false, finalized = false;
+  agx_config cfg;
+  GasDev gas;
+  SolverDev sp;
+  std::vector<Block> blocks;
+  std::vector<Conn> conns;
+  NormPartial* partials = nullptr;
+  long n_partials = 0;
+  NormPartial* norm_out = nullptr;      // device, one per block
+  NormPartial* norm_host = nullptr;     // pinned
+  int* err_dev = nullptr;
+  int* err_host = nullptr;              // pinned
+  double* halo_buf = nullptr;
+  long halo_cap = 0;
+  // timing: hipEvent pairs recorded on the library's stream around each
+  // kernel group, resolved lazily in agx_timing_get (no sync while running)
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  std::vector<std::pair<int, int>> ev_used;   // (group, pool index)
+  double t_ms[G_NGROUP] = {0, 0, 0, 0};
+  long t_n[G_NGROUP] = {0, 0, 0, 0};
+};
+
+namespace {
+
+void resolve_timing(agx_ctx* c);
+
+struct Timer {   // hipEvents on the library's stream around one kernel group
+  agx_ctx* c;
+  int slot = -1;
+  Timer(agx_ctx* ctx, int g) : c(ctx) {
+    if (!c->timing) return;
+    if (c->ev_used.size() >= 8192) resolve_timing(c);
+    slot = (int)c->ev_used.size();
+    if (slot >= (int)c->ev_pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        slot = -1;
+        return;
+      }
+      c->ev_pool.emplace_back(a, b);
+    }
+    c->ev_used.emplace_back(g, slot);
+    hipEventRecord(c->ev_pool[slot].first, c->stream);
+  }
+  ~Timer() {
+    if (slot >= 0) hipEventRecord(c->ev_pool[slot].second, c->stream);
+  }
+};
+
+void resolve_timing(agx_ctx* c) {
+  if (c->ev_used.empty()) return;
+  hipStreamSynchronize(c->stream);
+  for (auto& u : c->ev_used) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_pool[u.second].first,
+                            c->ev_pool[u.second].second) == hipSuccess) {
+      c->t_ms[u.first] += ms;
+      c->t_n[u.first] += 1;
+    }
+  }
+  c->ev_used.clear();
+}
+
+int derive_gas(const agx_config& cfg, GasDev& g) {
+  const agx_gas& a = cfg.gas;
+  g.R = a.gas_constant;
+  g.n = a.n;
+  g.hf = a.heat_of_formation;
+  g.cp = a.gas_constant * (a.n + 1.0);   // thermodynamic.hpp:108-113
+  g.cv = a.gas_constant * a.n;
+  g.gamma = g.cp / g.cv;
+  g.prandtl = (4.0 * g.gamma) / (9.0 * g.gamma - 5.0);
+  g.visc_c1 = a.visc_c1; g.visc_s = a.visc_s;
+  g.cond_c1 = a.cond_c1; g.cond_s = a.cond_s;
+  g.t_ref = a.t_ref;
+  g.mu_ref = a.visc_c1 * pow(a.t_ref, 1.5) / (a.t_ref + a.visc_s);  // transport.cpp:58-59
+  g.k_nondim = (a.a_ref * a.a_ref * g.mu_ref) / a.t_ref;            // :67
+  g.scaling = g.mu_ref / (a.rho_ref * a.a_ref * a.l_ref);            // transport.hpp:43-46
+  return 0;
+}
+
+dim3 cell_grid(const BlockDev& b, dim3 blk) {
+  return dim3((b.ni + blk.x - 1) / blk.x, (b.nj + blk.y - 1) / blk.y, b.nk);
+}
+const dim3 CELL_BLOCK(64, 4, 1);
+
+Planes5 planes(double* const* p, int n = AGX_NEQ) {
+  Planes5 r;
+  for (int e = 0; e < AGX_NEQ; ++e) r.p[e] = e < n ? p[e] : nullptr;
+  return r;
+}
+
+int alloc_plane(agx_ctx* c, Block& b, double** p) {
+  HIPCHK(hipMalloc((void**)p, sizeof(double) * b.d.nplane));
+  HIPCHK(hipMemsetAsync(*p, 0, sizeof(double) * b.d.nplane, c->stream));
+  b.allocs.push_back(*p);
+  return 0;
+}
+
+// upload an AoS host array (dims (ci,cj,ck) incl. gsrc ghosts, ncomp per cell)
+int upload_aos(agx_ctx* c, Block& b, const double* host, double* const* dst,
+               int ncomp, int ci, int cj, int ck, int gsrc) {
+  const long n = (long)ci * cj * ck;
+  double* tmp = nullptr;
+  HIPCHK(hipMalloc((void**)&tmp, sizeof(double) * n * ncomp));
+  HIPCHK(hipMemcpyAsync(tmp, host, sizeof(double) * n * ncomp,
+                        hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_aos_to_soa, dim3((n + 255) / 256), dim3(256), 0,
+                     c->stream, tmp, planes(dst, ncomp), ncomp, ci, cj, ck, gsrc, b.d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(tmp));
+  return 0;
+}
+int download_aos(agx_ctx* c, Block& b, double* host, double* const* src,
+                 int ncomp, int ci, int cj, int ck, int gsrc) {
+  const long n = (long)ci * cj * ck;
+  double* tmp = nullptr;
+  HIPCHK(hipMalloc((void**)&tmp, sizeof(double) * n * ncomp));
+  hipLaunchKernelGGL(k_soa_to_aos, dim3((n + 255) / 256), dim3(256), 0,
+                     c->stream, tmp, planes(src, ncomp), ncomp, ci, cj, ck, gsrc, b.d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(host, tmp, sizeof(double) * n * ncomp,
+                        hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(tmp));
+  return 0;
+}
+
+// ---- halo index maps: restates connection::First/SecondSliceIndices
+// (boundaryConditions.cpp:1016-1150), AdjustForSlice (:833-860), InsertSlice
+// (multiArray3d.hpp:868-918) and GetSwapLoc (boundaryConditions.cpp:3006-3181)
+// directly in device-index space.
+struct Dims { int n[3]; };
+struct MapOut { std::vector<long> dst, src; };
+
+void dirs_of(int boundary, int& d1, int& d2, int& d3) {
+  d3 = (boundary - 1) / 2;
+  d1 = (d3 + 1) % 3;
+  d2 = (d3 + 2) % 3;
+}
+// receiver = side `recv`; idxR/idxS give device indices for (i,j,k) in the
+// receiving / sending block
+template <class FR, class FS>
+void build_side_map(const agx_connection& cc, int recv, int ng, FR idxR, FS idxS,
+                    MapOut& out) {
+  const int snd = 1 - recv;
+  int orient = cc.orientation;
+  if (recv == 1) {                       // connection::SwapOrder :341-364
+    if (orient == 4) orient = 5; else if (orient == 5) orient = 4;
+  }
+  int rd1, rd2, rd3, sd1, sd2, sd3;
+  dirs_of(cc.boundary[recv], rd1, rd2, rd3);
+  dirs_of(cc.boundary[snd], sd1, sd2, sd3);
+  const int r_d1s = cc.d1_start[recv] - ng, r_d1e = cc.d1_end[recv] + ng;
+  const int r_d2s = cc.d2_start[recv] - ng, r_d2e = cc.d2_end[recv] + ng;
+  const bool r_upper = cc.boundary[recv] % 2 == 0;
+  const int blk_start = r_upper ? cc.const_surf[recv] : -ng;
+  const bool s_upper = cc.boundary[snd] % 2 == 0;
+  const int s_d3s = cc.const_surf[snd] + (s_upper ? -ng : 0);
+  const int s_d1s = cc.d1_start[snd] - ng, s_d2s = cc.d2_start[snd] - ng;
+  const int s_len1 = cc.d1_end[snd] - cc.d1_start[snd] + 2 * ng;
+  const int s_len2 = cc.d2_end[snd] - cc.d2_start[snd] + 2 * ng;
+  const int len1 = r_d1e - r_d1s, len2 = r_d2e - r_d2s;
+  const int32_t* pb = cc.patch_border + (recv == 0 ? 0 : 4);
+  const int aS1 = pb[0] ? ng : 0, aE1 = pb[1] ? ng : 0;
+  const int aS2 = pb[2] ? ng : 0, aE2 = pb[3] ? ng : 0;
+  const bool llu = (cc.boundary[0] + cc.boundary[1]) % 2 == 0;
+  for (int l3 = 0; l3 < ng; ++l3)
+    for (int l2 = aS2; l2 < len2 - aE2; ++l2)
+      for (int l1 = aS1; l1 < len1 - aE1; ++l1) {
+        int a[3], s[3], q1, q2;
+        a[rd1] = r_d1s + l1;
+        a[rd2] = r_d2s + l2;
+        a[rd3] = blk_start + l3;
+        if (orient == 2 || orient == 4 || orient == 5 || orient == 7) {
+          q2 = (orient == 5 || orient == 7) ? s_len2 - 1 - l1 : l1;
+          q1 = (orient == 4 || orient == 7) ? s_len1 - 1 - l2 : l2;
+        } else if (sd3 == 0) {           // i-patch rule, cpp:3064-3073
+          q1 = (orient == 6 || orient == 8) ? s_len1 - 1 - l1 : l1;
+          q2 = (orient == 3 || orient == 8) ? s_len2 - 1 - l2 : l2;
+        } else {
+          q1 = (orient == 3 || orient == 8) ? s_len1 - 1 - l1 : l1;
+          q2 = (orient == 6 || orient == 8) ? s_len2 - 1 - l2 : l2;
+        }
+        const int q3 = llu ? ng - l3 - 1 : l3;
+        s[sd1] = s_d1s + q1;
+        s[sd2] = s_d2s + q2;
+        s[sd3] = s_d3s + q3;
+        out.dst.push_back(idxR(a[0], a[1], a[2]));
+        out.src.push_back(idxS(s[0], s[1], s[2]));
+      }
+}
+
+int to_device(const std::vector<long>& v, long** out) {
+  *out = nullptr;
+  if (v.empty()) return 0;
+  HIPCHK(hipMalloc((void**)out, sizeof(long) * v.size()));
+  HIPCHK(hipMemcpy(*out, v.data(), sizeof(long) * v.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int ensure_halo_buf(agx_ctx* c, long ndoubles) {
+  if (ndoubles <= c->halo_cap) return 0;
+  if (c->halo_buf) HIPCHK(hipFree(c->halo_buf));
+  HIPCHK(hipMalloc((void**)&c->halo_buf, sizeof(double) * ndoubles));
+  c->halo_cap = ndoubles;
+  return 0;
+}
+
+double* const* halo_planes(Block& b, int what) {
+  return what == AGX_HALO_STATE ? b.d.state : b.d.x;
+}
+
+int check_device_error(agx_ctx* c) {
+  if (*c->err_host) {
+    *c->err_host = 0;
+    hipMemsetAsync(c->err_dev, 0, sizeof(int), c->stream);
+    return fail("a boundary-condition variant outside this build's coverage "
+                "was requested (nonreflecting inlet/outlet or heat-flux wall)");
+  }
+  return 0;
+}
+
+template <int RECON, int LIM>
+void launch_inv_flux(agx_ctx* c, const BlockDev& b, double cfl) {
+  const dim3 grid = cell_grid(b, CELL_BLOCK);
+  if (c->cfg.inviscid_flux == AGX_FLUX_ROE)
+    hipLaunchKernelGGL((k_inv_residual<RECON, LIM, AGX_FLUX_ROE>), grid,
+                       CELL_BLOCK, 0, c->stream, b, c->gas, c->sp, cfl);
+  else
+    hipLaunchKernelGGL((k_inv_residual<RECON, LIM, AGX_FLUX_AUSM>), grid,
+                       CELL_BLOCK, 0, c->stream, b, c->gas, c->sp, cfl);
+}
+template <int RECON>
+void launch_inv_lim(agx_ctx* c, const BlockDev& b, double cfl) {
+  switch (c->cfg.limiter) {
+    case AGX_LIMITER_VANALBADA: launch_inv_flux<RECON, AGX_LIMITER_VANALBADA>(c, b, cfl); break;
+    case AGX_LIMITER_MINMOD: launch_inv_flux<RECON, AGX_LIMITER_MINMOD>(c, b, cfl); break;
+    default: launch_inv_flux<RECON, AGX_LIMITER_NONE>(c, b, cfl); break;
+  }
+}
+void launch_inv(agx_ctx* c, const BlockDev& b, double cfl) {
+  switch (c->cfg.recon) {
+    case AGX_RECON_CONSTANT: launch_inv_flux<AGX_RECON_CONSTANT, AGX_LIMITER_NONE>(c, b, cfl); break;
+    case AGX_RECON_MUSCL: launch_inv_lim<AGX_RECON_MUSCL>(c, b, cfl); break;
+    case AGX_RECON_WENO: launch_inv_flux<AGX_RECON_WENO, AGX_LIMITER_NONE>(c, b, cfl); break;
+    default: launch_inv_flux<AGX_RECON_WENOZ, AGX_LIMITER_NONE>(c, b, cfl); break;
+  }
+}
+
+int bc_pass(agx_ctx* c, bool faces, int viscous) {
+  for (auto& blk : c->blocks) {
+    const BlockDev& b = blk.d;
+    if (faces) {
+      for (int sn = 0; sn < b.nsurf; ++sn) {
+        const agx_bc_surface& s = blk.surf_host[sn];
+        if (s.bc_type == AGX_BC_INTERBLOCK || s.bc_type == AGX_BC_PERIODIC) continue;
+        if (viscous && s.bc_type != AGX_BC_VISCOUSWALL) continue;
+        const int st = surface_type(s);
+        const int d3 = (st - 1) / 2, d1 = (d3 + 1) % 3, d2 = (d3 + 2) % 3;
+        const int lo[3] = {s.imin, s.jmin, s.kmin}, hi[3] = {s.imax, s.jmax, s.kmax};
+        const long n = (long)(hi[d1] - lo[d1]) * (hi[d2] - lo[d2]) * b.ng;
+        if (n <= 0) continue;
+        hipLaunchKernelGGL(k_bc_faces, dim3((n + 255) / 256), dim3(256), 0,
+                           c->stream, b, c->gas, sn, viscous, c->err_dev);
+      }
+    } else {
+      const long n = 4L * (b.ni + b.nj + b.nk);
+      hipLaunchKernelGGL(k_bc_edges, dim3((n + 127) / 128), dim3(128), 0,
+                         c->stream, b, c->gas, viscous, c->err_dev);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int reduce_norms(agx_ctx* c, size_t blk_index, long nparts) {
+  hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, c->stream,
+                     c->partials, nparts, c->norm_out + blk_index);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
+  const double alpha[4] = {0.25, 1.0 / 3.0, 0.5, 1.0};   // procBlock.cpp:938
+  {
+    Timer t(c, G_UPDATE);
+    for (size_t n = 0; n < c->blocks.size(); ++n) {
+      const BlockDev& b = c->blocks[n].d;
+      const dim3 grid = cell_grid(b, CELL_BLOCK);
+      const int last = mm == c->cfg.nonlinear_iterations - 1;
+      hipLaunchKernelGGL(k_update, grid, CELL_BLOCK, 0, c->stream, b, c->gas,
+                         c->sp, mode, mode == 1 ? alpha[mm & 3] : 1.0, last,
+                         c->partials);
+      if (reduce_norms(c, n, (long)grid.x * grid.y * grid.z)) return 1;
+    }
+  }
+  HIPCHK(hipMemcpyAsync(c->norm_host, c->norm_out,
+                        sizeof(NormPartial) * c->blocks.size(),
+                        hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->err_host, c->err_dev, sizeof(int),
+                        hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));   // the one sync per iteration
+  if (check_device_error(c)) return 1;
+  for (size_t n = 0; n < c->blocks.size(); ++n) {
+    const NormPartial& p = c->norm_host[n];
+    const BlockDev& b = c->blocks[n].d;
+    for (int e = 0; e < AGX_NEQ; ++e) l2[e] += p.l2[e];
+    if (p.vmax > linf->linf) {           // procBlock.cpp:863-866
+      long cell = p.lin / AGX_NEQ;
+      linf->linf = p.vmax;
+      linf->eqn = (int)(p.lin % AGX_NEQ) + 1;
+      linf->i = (int)(cell % b.ni);
+      linf->j = (int)((cell / b.ni) % b.nj);
+      linf->k = (int)(cell / ((long)b.ni * b.nj));
+      linf->block = b.parent;
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+const char* agx_last_error(void) { return g_err; }
+const char* agx_version(void) { return "aither_gfx950 0.1 (HIP, gfx950)"; }
+
+int agx_ctx_create(int device, int rank, agx_ctx** out) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail("no HIP device available (%s): the gfx950 library has no CPU "
+                "path", hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail("device %d out of range", device);
+  HIPCHK(hipSetDevice(device));
+  agx_ctx* c = new agx_ctx();
+  c->device = device;
+  c->rank = rank;
+  HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
+  HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
+  HIPCHK(hipHostMalloc((void**)&c->err_host, sizeof(int)));
+  *c->err_host = 0;
+  *out = c;
+  return 0;
+}
+
+void agx_ctx_destroy(agx_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (auto& b : c->blocks) {
+    for (double* p : b.allocs) hipFree(p);
+    if (b.surf_dev) hipFree(b.surf_dev);
+  }
+  for (auto& k : c->conns) {
+    for (int s = 0; s < 2; ++s) {
+      if (k.side[s].dst) hipFree(k.side[s].dst);
+      if (k.side[s].src) hipFree(k.side[s].src);
+    }
+    if (k.send_src) hipFree(k.send_src);
+  }
+  if (c->partials) hipFree(c->partials);
+  if (c->norm_out) hipFree(c->norm_out);
+  if (c->norm_host) hipHostFree(c->norm_host);
+  if (c->err_dev) hipFree(c->err_dev);
+  if (c->err_host) hipHostFree(c->err_host);
+  if (c->halo_buf) hipFree(c->halo_buf);
+  for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  delete c;
+}
+
+int agx_ctx_set_stream(agx_ctx* c, void* s) {
+  c->stream = (hipStream_t)s;
+  return 0;
+}
+
+int agx_config_set(agx_ctx* c, const agx_config* cfg) {
+  if (cfg->n_eq != AGX_NEQ)
+    return fail("n_eq = %d: this build covers the 5-equation single-species "
+                "set", cfg->n_eq);
+  if (cfg->n_ghost < 1 || cfg->n_ghost > 3) return fail("n_ghost out of range");
+  c->cfg = *cfg;
+  derive_gas(*cfg, c->gas);
+  SolverDev& sp = c->sp;
+  sp.kappa = cfg->kappa;
+  sp.theta = cfg->theta;
+  sp.zeta = cfg->zeta;
+  sp.relax = cfg->matrix_relaxation;
+  sp.dual_time_cfl = cfg->dual_time_cfl;
+  sp.dt_fixed = cfg->dt_nondim;
+  sp.visc_cfl_coeff = cfg->viscous_cfl_coeff;
+  sp.viscous = cfg->is_viscous;
+  sp.implicit = cfg->time_integration >= AGX_TIME_IMPLICIT_EULER;
+  sp.bdf2 = cfg->time_integration == AGX_TIME_BDF2;
+  // input::MatrixRequiresInitialization input.cpp:1120-1125
+  sp.requires_init = cfg->matrix_solver == AGX_SOLVER_DPLUR || cfg->matrix_sweeps > 1;
+  sp.time_integration = cfg->time_integration;
+  c->have_cfg = true;
+  return 0;
+}
+
+int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
+  if (!c->have_cfg) return fail("agx_config_set must precede agx_block_create");
+  if (g->ng != c->cfg.n_ghost) return fail("block ghost layers != config n_ghost");
+  if (g->ni < 1 || g->nj < 1 || g->nk < 1) return fail("empty block");
+  HIPCHK(hipSetDevice(c->device));
+  c->blocks.emplace_back();
+  Block& b = c->blocks.back();
+  BlockDev& d = b.d;
+  memset(&d, 0, sizeof d);
+  d.ni = g->ni; d.nj = g->nj; d.nk = g->nk; d.ng = g->ng;
+  d.parent = g->parent_block;
+  b.global_pos = g->global_pos;
+  d.ioff = 16;                               // physical i = 0 on a 128-B line
+  const long row = d.ioff + d.ni + d.ng + 1; // +1: upper i-face
+  d.sx = (row + 15) / 16 * 16;
+  d.sxy = d.sx * (d.nj + 2 * d.ng + 1);
+  d.nplane = d.sxy * (d.nk + 2 * d.ng + 1);
+  double** cellp[] = {&d.vol, &d.specrad, &d.dt, &d.a, &d.ainv};
+  for (auto p : cellp) if (alloc_plane(c, b, p)) return 1;
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    double** ps[] = {&d.state[e], &d.resid[e], &d.consn[e], &d.consnm1[e],
+                     &d.x[e], &d.xold[e]};
+    for (auto p : ps) if (alloc_plane(c, b, p)) return 1;
+  }
+  for (int q = 0; q < 3; ++q) {
+    if (alloc_plane(c, b, &d.cen[q])) return 1;
+    if (alloc_plane(c, b, &d.wid[q])) return 1;
+    for (int cc = 0; cc < 4; ++cc) if (alloc_plane(c, b, &d.fa[q][cc])) return 1;
+  }
+  const int ci = d.ni + 2 * d.ng, cj = d.nj + 2 * d.ng, ck = d.nk + 2 * d.ng;
+  if (upload_aos(c, b, g->farea_i, d.fa[0], 4, ci + 1, cj, ck, d.ng)) return 1;
+  if (upload_aos(c, b, g->farea_j, d.fa[1], 4, ci, cj + 1, ck, d.ng)) return 1;
+  if (upload_aos(c, b, g->farea_k, d.fa[2], 4, ci, cj, ck + 1, d.ng)) return 1;
+  double* volp[1] = {d.vol};
+  if (upload_aos(c, b, g->vol, volp, 1, ci, cj, ck, d.ng)) return 1;
+  if (upload_aos(c, b, g->center, d.cen, 3, ci, cj, ck, d.ng)) return 1;
+  const double* wsrc[3] = {g->width_i, g->width_j, g->width_k};
+  for (int q = 0; q < 3; ++q) {
+    double* wp[1] = {d.wid[q]};
+    if (upload_aos(c, b, wsrc[q], wp, 1, ci, cj, ck, d.ng)) return 1;
+  }
+  *block_id = (int)c->blocks.size() - 1;
+  return 0;
+}
+
+int agx_block_set_bcs(agx_ctx* c, int id, int n, const agx_bc_surface* s) {
+  if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
+  Block& b = c->blocks[id];
+  b.surf_host.assign(s, s + n);
+  if (b.surf_dev) HIPCHK(hipFree(b.surf_dev));
+  HIPCHK(hipMalloc((void**)&b.surf_dev, sizeof(agx_bc_surface) * (n > 0 ? n : 1)));
+  HIPCHK(hipMemcpy(b.surf_dev, s, sizeof(agx_bc_surface) * n, hipMemcpyHostToDevice));
+  b.d.surf = b.surf_dev;
+  b.d.nsurf = n;
+  b.d.nsurf_i = b.d.nsurf_j = b.d.nsurf_k = 0;
+  for (int q = 0; q < n; ++q) {
+    const int st = surface_type(s[q]);
+    if (st <= 2) b.d.nsurf_i++; else if (st <= 4) b.d.nsurf_j++; else b.d.nsurf_k++;
+    const int t = s[q].bc_type;
+    if (t < AGX_BC_SLIPWALL || t > AGX_BC_PERIODIC) return fail("unknown bc type %d", t);
+  }
+  return 0;
+}
+
+int agx_conn_create(agx_ctx* c, const agx_connection* cc, int* conn_id) {
+  c->conns.emplace_back();
+  c->conns.back().c = *cc;
+  *conn_id = (int)c->conns.size() - 1;
+  return 0;
+}
+
+int agx_setup_finalize(agx_ctx* c) {
+  HIPCHK(hipSetDevice(c->device));
+  const int ng = c->cfg.n_ghost;
+  long max_parts = 1, max_halo = 1;
+  for (auto& blk : c->blocks) {
+    const dim3 g = cell_grid(blk.d, CELL_BLOCK);
+    max_parts = std::max(max_parts, (long)g.x * g.y * g.z);
+  }
+  for (auto& k : c->conns) {
+    const agx_connection& cc = k.c;
+    const bool l0 = cc.rank[0] == c->rank, l1 = cc.rank[1] == c->rank;
+    if (!l0 && !l1) continue;
+    for (int s = 0; s < 2; ++s) {
+      const bool mine = s == 0 ? l0 : l1, partner_mine = s == 0 ? l1 : l0;
+      if (!mine) continue;
+      const int lb = cc.local_block[s];
+      if (lb < 0 || lb >= (int)c->blocks.size()) return fail("connection refers to unknown block");
+      const BlockDev& br = c->blocks[lb].d;
+      auto idxR = [&](int i, int j, int kk) { return br.idx(i, j, kk); };
+      MapOut m;
+      if (partner_mine) {
+        const BlockDev& bs = c->blocks[cc.local_block[1 - s]].d;
+        auto idxS = [&](int i, int j, int kk) { return bs.idx(i, j, kk); };
+        build_side_map(cc, s, ng, idxR, idxS, m);
+      } else {
+        auto idxS = [&](int, int, int) { return 0L; };
+        build_side_map(cc, s, ng, idxR, idxS, m);
+        // cells of my block the partner's ghost cells read, in the partner's
+        // insertion order (what agx_halo_pack sends)
+        MapOut ms;
+        auto idxRp = [&](int, int, int) { return 0L; };
+        build_side_map(cc, 1 - s, ng, idxRp, idxR, ms);
+        k.n_send = (long)ms.src.size();
+        if (to_device(ms.src, &k.send_src)) return 1;
+        max_halo = std::max(max_halo, (long)ms.src.size() * AGX_NEQ);
+      }
+      k.side[s].n = (long)m.dst.size();
+      if (to_device(m.dst, &k.side[s].dst)) return 1;
+      if (partner_mine && to_device(m.src, &k.side[s].src)) return 1;
+      max_halo = std::max(max_halo, (long)m.dst.size() * AGX_NEQ);
+    }
+  }
+  if (ensure_halo_buf(c, 2 * max_halo)) return 1;
+  c->n_partials = max_parts;
+  HIPCHK(hipMalloc((void**)&c->partials, sizeof(NormPartial) * max_parts));
+  const size_t nb = std::max<size_t>(c->blocks.size(), 1);
+  HIPCHK(hipMalloc((void**)&c->norm_out, sizeof(NormPartial) * nb));
+  HIPCHK(hipHostMalloc((void**)&c->norm_host, sizeof(NormPartial) * nb));
+  c->finalized = true;
+  return 0;
+}
+
+int agx_state_upload(agx_ctx* c, int id, const double* state) {
+  if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
+  Block& b = c->blocks[id];
+  const BlockDev& d = b.d;
+  return upload_aos(c, b, state, d.state, AGX_NEQ, d.ni + 2 * d.ng,
+                    d.nj + 2 * d.ng, d.nk + 2 * d.ng, d.ng);
+}
+
+static int field_info(Block& b, int field, double* const** p, int* ncomp, int* ghost) {
+  BlockDev& d = b.d;
+  static thread_local double* one[1];
+  switch (field) {
+    case AGX_FIELD_STATE: *p = d.state; *ncomp = AGX_NEQ; *ghost = 1; return 0;
+    case AGX_FIELD_RESIDUAL: *p = d.resid; *ncomp = AGX_NEQ; *ghost = 0; return 0;
+    case AGX_FIELD_CONS_N: *p = d.consn; *ncomp = AGX_NEQ; *ghost = 0; return 0;
+    case AGX_FIELD_CONS_NM1: *p = d.consnm1; *ncomp = AGX_NEQ; *ghost = 0; return 0;
+    case AGX_FIELD_UPDATE: *p = d.x; *ncomp = AGX_NEQ; *ghost = 1; return 0;
+    case AGX_FIELD_DT: one[0] = d.dt; *p = one; *ncomp = 1; *ghost = 0; return 0;
+    case AGX_FIELD_SPEC_RADIUS: one[0] = d.specrad; *p = one; *ncomp = 1; *ghost = 0; return 0;
+    case AGX_FIELD_DIAGONAL: one[0] = d.a; *p = one; *ncomp = 1; *ghost = 0; return 0;
+  }
+  return 1;
+}
+
+int agx_field_download(agx_ctx* c, int id, int field, double* out) {
+  if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
+  Block& b = c->blocks[id];
+  double* const* p; int nc, gh;
+  if (field_info(b, field, &p, &nc, &gh))
+    return fail("field %d is not stored by this library (temperature and "
+                "viscosity are recomputed from the state on device)", field);
+  const int g = gh ? b.d.ng : 0;
+  return download_aos(c, b, out, p, nc, b.d.ni + 2 * g, b.d.nj + 2 * g, b.d.nk + 2 * g, g);
+}
+int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
+  if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
+  Block& b = c->blocks[id];
+  double* const* p; int nc, gh;
+  if (field_info(b, field, &p, &nc, &gh)) return fail("field %d cannot be uploaded", field);
+  const int g = gh ? b.d.ng : 0;
+  return upload_aos(c, b, in, p, nc, b.d.ni + 2 * g, b.d.nj + 2 * g, b.d.nk + 2 * g, g);
+}
+
+int agx_store_time_n(agx_ctx* c, int also_nm1) {
+  for (auto& blk : c->blocks)
+    hipLaunchKernelGGL(k_store_time_n, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
+                       0, c->stream, blk.d, c->gas, also_nm1);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- phases ---------------------------------------------------------------
+int agx_phase_bc_faces(agx_ctx* c) { Timer t(c, G_BC); return bc_pass(c, true, 0); }
+int agx_phase_bc_edges(agx_ctx* c) { Timer t(c, G_BC); return bc_pass(c, false, 0); }
+
+int agx_phase_residual(agx_ctx* c, double cfl) {
+  if (c->cfg.dt_nondim <= 0.0 && cfl <= 0.0)
+    return fail("Neither dt or cfl was specified!");   // procBlock.cpp:813-816
+  {
+    Timer t(c, G_RESID);
+    for (auto& blk : c->blocks) launch_inv(c, blk.d, cfl);
+  }
+  HIPCHK(hipGetLastError());
+  if (c->cfg.is_viscous) {
+    {
+      Timer t(c, G_BC);
+      if (bc_pass(c, true, 1)) return 1;
+      if (bc_pass(c, false, 1)) return 1;
+    }
+    Timer t(c, G_RESID);
+    for (auto& blk : c->blocks)
+      hipLaunchKernelGGL(k_visc_residual, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
+                         0, c->stream, blk.d, c->gas, c->sp, cfl);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+int agx_phase_explicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
+  const int mode = c->cfg.time_integration == AGX_TIME_RK4 ? 1 : 0;
+  return update_pass(c, mode, mm, l2, linf);
+}
+
+int agx_phase_implicit_begin(agx_ctx* c) {
+  Timer t(c, G_SWEEP);
+  for (auto& blk : c->blocks) {
+    const BlockDev& b = blk.d;
+    if (!c->sp.requires_init)   // x_[bb].Zero() incl. ghosts, linearSolver.cpp:141
+      hipLaunchKernelGGL(k_zero5, dim3((b.nplane + 255) / 256), dim3(256), 0,
+                         c->stream, planes(b.x), b.nplane);
+    hipLaunchKernelGGL(k_implicit_begin, cell_grid(b, CELL_BLOCK), CELL_BLOCK, 0,
+                       c->stream, b, c->gas, c->sp);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int agx_phase_relax_forward(agx_ctx* c, int sweep) {
+  Timer t(c, G_SWEEP);
+  const int full = sweep > 0 || c->sp.requires_init;
+  for (auto& blk : c->blocks) {
+    const BlockDev& b = blk.d;
+    if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
+      const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
+      const int nplanes = b.ni + b.nj + b.nk - 2;
+      for (int p = 0; p < nplanes; ++p)
+        hipLaunchKernelGGL((k_lusgs_plane<true>), grid, tb, 0, c->stream, b,
+                           c->gas, c->sp, p, full);
+    } else {
+      hipLaunchKernelGGL(k_copy5, dim3((b.nplane + 255) / 256), dim3(256), 0,
+                         c->stream, planes(b.xold), planes(b.x), b.nplane);
+      hipLaunchKernelGGL(k_dplur, cell_grid(b, CELL_BLOCK), CELL_BLOCK, 0,
+                         c->stream, b, c->gas, c->sp);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int agx_phase_relax_backward(agx_ctx* c, int sweep) {
+  if (c->cfg.matrix_solver != AGX_SOLVER_LUSGS) return 0;
+  Timer t(c, G_SWEEP);
+  const int full = sweep > 0 || c->sp.requires_init;
+  for (auto& blk : c->blocks) {
+    const BlockDev& b = blk.d;
+    const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
+    const int nplanes = b.ni + b.nj + b.nk - 2;
+    for (int p = nplanes - 1; p >= 0; --p)
+      hipLaunchKernelGGL((k_lusgs_plane<false>), grid, tb, 0, c->stream, b,
+                         c->gas, c->sp, p, full);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
+  double sumsq = 0.0;
+  long size = 0;
+  {
+    Timer t(c, G_SWEEP);
+    for (size_t n = 0; n < c->blocks.size(); ++n) {
+      const BlockDev& b = c->blocks[n].d;
+      const dim3 grid = cell_grid(b, CELL_BLOCK);
+      hipLaunchKernelGGL(k_matrix_resid, grid, CELL_BLOCK, 0, c->stream, b,
+                         c->gas, c->sp, c->partials);
+      if (reduce_norms(c, n, (long)grid.x * grid.y * grid.z)) return 1;
+    }
+  }
+  HIPCHK(hipMemcpyAsync(c->norm_host, c->norm_out,
+                        sizeof(NormPartial) * c->blocks.size(),
+                        hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (size_t n = 0; n < c->blocks.size(); ++n) {
+    const BlockDev& b = c->blocks[n].d;
+    for (int e = 0; e < AGX_NEQ; ++e) sumsq += c->norm_host[n].l2[e];
+    // mr.Size(): ghost-inclusive (linearSolver.cpp:66-68, mgSolution.cpp:203)
+    size += (long)AGX_NEQ * (b.ni + 2 * b.ng) * (b.nj + 2 * b.ng) * (b.nk + 2 * b.ng);
+  }
+  *mr = size > 0 ? sumsq / (double)size : 0.0;
+  return 0;
+}
+
+int agx_phase_implicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
+  return update_pass(c, 2, mm, l2, linf);
+}
+
+// ---- halo -----------------------------------------------------------------
+int agx_halo_swap_local(agx_ctx* c, int what) {
+  Timer t(c, G_BC);
+  for (auto& k : c->conns) {
+    const agx_connection& cc = k.c;
+    if (!(cc.rank[0] == c->rank && cc.rank[1] == c->rank)) continue;
+    Block& b0 = c->blocks[cc.local_block[0]];
+    Block& b1 = c->blocks[cc.local_block[1]];
+    const long n0 = k.side[0].n, n1 = k.side[1].n;
+    if (ensure_halo_buf(c, (n0 + n1) * AGX_NEQ)) return 1;
+    double* buf0 = c->halo_buf;                 // what side 0 receives
+    double* buf1 = c->halo_buf + n0 * AGX_NEQ;  // what side 1 receives
+    // both slices are taken before either insert (multiArray3d.hpp:810-821)
+    if (n0) hipLaunchKernelGGL(k_halo_gather, dim3((n0 + 255) / 256), dim3(256), 0,
+                               c->stream, planes(halo_planes(b1, what)), k.side[0].src, n0, buf0);
+    if (n1) hipLaunchKernelGGL(k_halo_gather, dim3((n1 + 255) / 256), dim3(256), 0,
+                               c->stream, planes(halo_planes(b0, what)), k.side[1].src, n1, buf1);
+    if (n0) hipLaunchKernelGGL(k_halo_scatter, dim3((n0 + 255) / 256), dim3(256), 0,
+                               c->stream, planes(halo_planes(b0, what)), k.side[0].dst, n0, buf0);
+    if (n1) hipLaunchKernelGGL(k_halo_scatter, dim3((n1 + 255) / 256), dim3(256), 0,
+                               c->stream, planes(halo_planes(b1, what)), k.side[1].dst, n1, buf1);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int my_side(const agx_ctx* c, const Conn& k) {
+  if (k.c.rank[0] == c->rank && k.c.rank[1] != c->rank) return 0;
+  if (k.c.rank[1] == c->rank && k.c.rank[0] != c->rank) return 1;
+  return -1;
+}
+int64_t agx_halo_count(agx_ctx* c, int id, int what) {
+  (void)what;
+  if (id < 0 || id >= (int)c->conns.size()) return -1;
+  const Conn& k = c->conns[id];
+  const int s = my_side(c, k);
+  if (s < 0) return 0;
+  return (int64_t)AGX_NEQ * std::max(k.n_send, k.side[s].n);
+}
+int agx_halo_pack(agx_ctx* c, int id, int what, double* dev_buf) {
+  if (id < 0 || id >= (int)c->conns.size()) return fail("bad connection id");
+  Conn& k = c->conns[id];
+  const int s = my_side(c, k);
+  if (s < 0) return fail("connection %d is not remote", id);
+  Block& b = c->blocks[k.c.local_block[s]];
+  const long n = k.n_send;
+  if (n) hipLaunchKernelGGL(k_halo_gather, dim3((n + 255) / 256), dim3(256), 0,
+                            c->stream, planes(halo_planes(b, what)), k.send_src, n, dev_buf);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int agx_halo_unpack(agx_ctx* c, int id, int what, const double* dev_buf) {
+  if (id < 0 || id >= (int)c->conns.size()) return fail("bad connection id");
+  Conn& k = c->conns[id];
+  const int s = my_side(c, k);
+  if (s < 0) return fail("connection %d is not remote", id);
+  Block& b = c->blocks[k.c.local_block[s]];
+  const long n = k.side[s].n;
+  if (n) hipLaunchKernelGGL(k_halo_scatter, dim3((n + 255) / 256), dim3(256), 0,
+                            c->stream, planes(halo_planes(b, what)), k.side[s].dst, n, dev_buf);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- mgSolution::Iterate (mgSolution.cpp:246-269) ---------------------------
+int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
+                double* matrix_resid) {
+  if (!c->finalized) return fail("agx_setup_finalize has not been called");
+  for (auto& k : c->conns)
+    if (my_side(c, k) >= 0)
+      return fail("agx_iterate: remote connections need the phase API");
+  // gridLevel::GetBoundaryConditions gridLevel.cpp:287-319
+  if (agx_phase_bc_faces(c)) return 1;
+  if (agx_halo_swap_local(c, AGX_HALO_STATE)) return 1;
+  if (agx_phase_bc_edges(c)) return 1;
+  // gridLevel::CalcResidual :372-400 + CalcTimeStep :240-247
+  if (agx_phase_residual(c, cfl)) return 1;
+  *matrix_resid = 0.0;
+  if (c->sp.implicit) {
+    // mgSolution::ImplicitUpdate :209-244; lusgs::Relax linearSolver.cpp:430-470;
+    // dplur::Relax :509-535
+    if (agx_phase_implicit_begin(c)) return 1;
+    for (int s = 0; s < c->cfg.matrix_sweeps; ++s) {
+      if (agx_halo_swap_local(c, AGX_HALO_UPDATE)) return 1;
+      if (agx_phase_relax_forward(c, s)) return 1;
+      if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
+        if (agx_halo_swap_local(c, AGX_HALO_UPDATE)) return 1;
+        if (agx_phase_relax_backward(c, s)) return 1;
+      }
+    }
+    if (agx_halo_swap_local(c, AGX_HALO_UPDATE)) return 1;
+    if (agx_phase_matrix_residual(c, matrix_resid)) return 1;
+    return agx_phase_implicit_update(c, mm, l2, linf);
+  }
+  return agx_phase_explicit_update(c, mm, l2, linf);
+}
+
+// ---- measurement ------------------------------------------------------------
+int agx_timing_enable(agx_ctx* c, int on) {
+  if (!on) resolve_timing(c);
+  c->timing = on != 0;
+  return 0;
+}
+int agx_timing_get(agx_ctx* c, int group, double* avg_ms, int64_t* launches) {
+  if (group < 0 || group >= G_NGROUP) return fail("bad timing group");
+  resolve_timing(c);
+  *launches = c->t_n[group];
+  *avg_ms = c->t_n[group] ? c->t_ms[group] / c->t_n[group] : 0.0;
+  return 0;
+}
+int agx_timing_reset(agx_ctx* c) {
+  resolve_timing(c);
+  for (int g = 0; g < G_NGROUP; ++g) { c->t_ms[g] = 0.0; c->t_n[g] = 0; }
+  return 0;
+}
+int agx_sync(agx_ctx* c) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+}  // extern "C"

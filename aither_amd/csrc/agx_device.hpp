@@ -1,0 +1,541 @@
+// agx_device.hpp -- device-side numerics primitives for gfx950 (fp64).
+//
+// Per-cell/per-face register work shared by all kernels: thermodynamics,
+// face reconstruction, Riemann fluxes, spectral radii, ghost-state rules.
+// Each function names the reference function it is the counterpart of
+// (paths relative to the reference root); the arithmetic is free to differ in
+// operand order / FMA contraction -- parity with the CPU oracle is asserted to
+// 1e-10 relative by tests/test_parity_gpu.py, not bitwise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/aither_gfx950.h"
+
+#define AGX_NEQ 5
+#define AGX_EPS 1.0e-30  // include/macros.hpp.in:20
+
+namespace agx {
+
+// gas model constants resolved once on the host (agx_api.hip: derive_gas)
+struct GasDev {
+  double R;        // nondimensional gas constant
+  double n;        // cv = n R
+  double hf;       // heat of formation
+  double gamma;    // cp / cv
+  double cp, cv;
+  double prandtl;  // 4 gamma / (9 gamma - 5)   thermodynamic.hpp:60-63
+  double visc_c1, visc_s, cond_c1, cond_s, t_ref;
+  double mu_ref;    // sutherland::muMixRef_     transport.cpp:64-66
+  double k_nondim;  // sutherland::kNonDim_      transport.cpp:67
+  double scaling;   // transport::NondimScaling  transport.hpp:43-46
+};
+
+struct Prim {  // primitive: rho, u, v, w, p  (varArray.hpp:40-51)
+  double v[AGX_NEQ];
+};
+
+__device__ __forceinline__ double dot3(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+// idealGas::Temperature eos.cpp:100-109
+__device__ __forceinline__ double temperature(const GasDev& g, const double* s) {
+  return s[4] / (s[0] * g.R);
+}
+// SpeedOfSound arrayView.hpp:383-391
+__device__ __forceinline__ double sound_speed(const GasDev& g, const double* s) {
+  return sqrt(g.gamma * s[4] / s[0]);
+}
+// EnthalpyFunc arrayView.hpp:401-409 (|v| via sqrt then squared, eos.cpp:80-84)
+__device__ __forceinline__ double enthalpy(const GasDev& g, const double* s) {
+  const double t = temperature(g, s);
+  const double vel = sqrt(dot3(s + 1, s + 1));
+  return g.hf + g.R * (g.n + 1.0) * t + 0.5 * vel * vel;
+}
+// InternalEnergy arrayView.hpp:434-443
+__device__ __forceinline__ double total_energy(const GasDev& g, const double* s) {
+  const double t = temperature(g, s);
+  const double vel = sqrt(dot3(s + 1, s + 1));
+  return g.hf + g.R * g.n * t + 0.5 * vel * vel;
+}
+// PrimToCons primitive.hpp:183-201
+__device__ __forceinline__ void prim_to_cons(const GasDev& g, const double* s,
+                                             double* u) {
+  u[0] = s[0];
+  u[1] = s[0] * s[1];
+  u[2] = s[0] * s[2];
+  u[3] = s[0] * s[3];
+  u[4] = s[0] * total_energy(g, s);
+}
+// primitive(cons, phys) primitive.hpp:152-178, idealGas::PressFromEnergy
+// eos.cpp:40-52, TemperatureFromSpecEnergy thermodynamic.cpp:108-114
+__device__ __forceinline__ void cons_to_prim(const GasDev& g, const double* u,
+                                             double* s) {
+  const double rho = u[0];
+  s[0] = rho;
+  s[1] = u[1] / rho;
+  s[2] = u[2] / rho;
+  s[3] = u[3] / rho;
+  const double en = u[4] / rho;
+  const double vel = sqrt(dot3(s + 1, s + 1));
+  const double spec = en - 0.5 * vel * vel;
+  const double t = (spec - g.hf) / g.cv;
+  s[4] = rho * g.R * t;
+}
+// UpdatePrimWithCons primitive.hpp:206-231
+__device__ __forceinline__ void update_prim_with_cons(const GasDev& g,
+                                                      const double* s,
+                                                      const double* du,
+                                                      double* out) {
+  double u[AGX_NEQ];
+  prim_to_cons(g, s, u);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) u[e] += du[e];
+  cons_to_prim(g, u, out);
+}
+// sutherland::SpeciesViscosity transport.cpp:114-122
+__device__ __forceinline__ double viscosity(const GasDev& g, double t) {
+  const double temp = t * g.t_ref;
+  return (g.visc_c1 * temp * sqrt(temp)) / (temp + g.visc_s) / g.mu_ref;
+}
+// sutherland::SpeciesConductivity transport.cpp:124-132
+__device__ __forceinline__ double conductivity(const GasDev& g, double t) {
+  const double temp = t * g.t_ref;
+  return (g.cond_c1 * temp * sqrt(temp)) / (temp + g.cond_s) / g.k_nondim;
+}
+
+// ---- limiters src/limiter.cpp:24-54 ---------------------------------------
+template <int LIM>
+__device__ __forceinline__ double limiter(double r) {
+  if (LIM == AGX_LIMITER_VANALBADA) {
+    const double r2 = r * r;
+    return fmax(0.0, (r + r2) / (1.0 + r2));
+  } else if (LIM == AGX_LIMITER_MINMOD) {
+    return fmax(0.0, fmin(1.0, r));
+  }
+  return 1.0;
+}
+
+// FaceReconMUSCL reconstruction.hpp:110-154, one variable
+template <int LIM>
+__device__ __forceinline__ double muscl(double uw2, double uw1, double dw1,
+                                        double dPlus, double dMinus,
+                                        double kappa) {
+  const double dm = (uw1 - uw2) * dMinus;
+  const double r = (AGX_EPS + (dw1 - uw1) * dPlus) / (AGX_EPS + dm);
+  double lim = 1.0, inv = 1.0;
+  if (LIM != AGX_LIMITER_NONE) {
+    lim = limiter<LIM>(r);
+    inv = limiter<LIM>(1.0 / r);
+  }
+  return uw1 + 0.25 * dm * ((1.0 - kappa) * lim + (1.0 + kappa) * r * inv);
+}
+
+// ---- WENO5 on non-uniform widths, reconstruction.hpp:158-310 --------------
+// LagrangeCoeff src/utility.cpp:449-483 (width-only; evaluated per face side)
+__device__ __forceinline__ double stencil_width(const double* w, int s, int e) {
+  double acc = 0.0;
+  if (e > s) {
+    for (int q = s; q < e; ++q) acc += w[q];
+  } else if (s > e) {
+    for (int q = e; q < s; ++q) acc += w[q];
+    acc = -acc;
+  }
+  return acc;
+}
+template <int DEGREE>
+__device__ __forceinline__ void lagrange_coeff(const double* w, int rr, int ii,
+                                               double* coeffs) {
+#pragma unroll
+  for (int jj = 0; jj <= DEGREE; ++jj) {
+    double c = 0.0;
+#pragma unroll
+    for (int mm = jj + 1; mm <= DEGREE + 1; ++mm) {
+      double numer = 0.0, denom = 1.0;
+#pragma unroll
+      for (int ll = 0; ll <= DEGREE + 1; ++ll) {
+        if (ll != mm) {
+          double prod = 1.0;
+#pragma unroll
+          for (int qq = 0; qq <= DEGREE + 1; ++qq)
+            if (qq != mm && qq != ll)
+              prod *= stencil_width(w, ii - rr + qq, ii + 1);
+          numer += prod;
+          denom *= stencil_width(w, ii - rr + ll, ii - rr + mm);
+        }
+      }
+      c += numer / denom;
+    }
+    coeffs[jj] = c * w[ii - rr + jj];
+  }
+}
+struct WenoCoeffs {  // everything that depends on cell widths only
+  double c0[3], c1[3], c2[3], lw0, lw1, lw2;
+};
+__device__ __forceinline__ void weno_coeffs(const double* cw, WenoCoeffs& k) {
+  double cf[5];
+  lagrange_coeff<2>(cw, 2, 2, k.c0);
+  lagrange_coeff<2>(cw, 1, 2, k.c1);
+  lagrange_coeff<2>(cw, 0, 2, k.c2);
+  lagrange_coeff<4>(cw, 2, 2, cf);
+  k.lw0 = cf[0] / k.c0[0];
+  k.lw1 = cf[4] / k.c2[2];
+  k.lw2 = 1.0 - k.lw0 - k.lw1;
+}
+// Derivative2nd utility.hpp:114-120, BetaIntegral / Beta0/1/2
+// reconstruction.hpp:158-240
+__device__ __forceinline__ double beta_int(double d1, double d2, double dx,
+                                           double xl, double xh) {
+  const double dx3 = dx * dx * dx;
+  const double fh = (d1 * d1 * xh + d1 * d2 * xh * xh +
+                     d2 * d2 * (xh * xh * xh) / 3.0) * dx + d2 * d2 * xh * dx3;
+  const double fl = (d1 * d1 * xl + d1 * d2 * xl * xl +
+                     d2 * d2 * (xl * xl * xl) / 3.0) * dx + d2 * d2 * xl * dx3;
+  return fh - fl;
+}
+__device__ __forceinline__ double deriv2(double x0, double x1, double x2,
+                                         double y0, double y1, double y2) {
+  const double fwd = (y2 - y1) / (0.5 * (x2 + x1));
+  const double bck = (y1 - y0) / (0.5 * (x1 + x0));
+  return (fwd - bck) / (0.25 * (x2 + x0) + 0.5 * x1);
+}
+template <bool WENOZ>
+__device__ __forceinline__ double weno(const WenoCoeffs& k, const double* cw,
+                                       double u3, double u2, double u1,
+                                       double d1, double d2) {
+  const double s0 = k.c0[0] * u3 + k.c0[1] * u2 + k.c0[2] * u1;
+  const double s1 = k.c1[0] * u2 + k.c1[1] * u1 + k.c1[2] * d1;
+  const double s2 = k.c2[0] * u1 + k.c2[1] * d1 + k.c2[2] * d2;
+  double b0, b1, b2;
+  {
+    const double dd = deriv2(cw[0], cw[1], cw[2], u3, u2, u1);
+    const double df = (u1 - u2) / (0.5 * (cw[2] + cw[1])) + 0.5 * cw[2] * dd;
+    b0 = beta_int(df, dd, cw[2], -0.5 * cw[2], 0.5 * cw[2]);
+  }
+  {
+    const double dd = deriv2(cw[1], cw[2], cw[3], u2, u1, d1);
+    const double df = (d1 - u1) / (0.5 * (cw[3] + cw[2])) - 0.5 * cw[2] * dd;
+    b1 = beta_int(df, dd, cw[2], -0.5 * cw[2], 0.5 * cw[2]);
+  }
+  {
+    const double dd = deriv2(cw[2], cw[3], cw[4], u1, d1, d2);
+    const double df = (d1 - u1) / (0.5 * (cw[3] + cw[2])) - 0.5 * cw[2] * dd;
+    b2 = beta_int(df, dd, cw[2], -0.5 * cw[2], 0.5 * cw[2]);
+  }
+  double n0, n1, n2;
+  if (WENOZ) {
+    const double tau5 = fabs(b0 - b2);
+    const double q0 = tau5 / (1.0e-40 + b0), q1 = tau5 / (1.0e-40 + b1),
+                 q2 = tau5 / (1.0e-40 + b2);
+    n0 = k.lw0 * (1.0 + q0 * q0);
+    n1 = k.lw1 * (1.0 + q1 * q1);
+    n2 = k.lw2 * (1.0 + q2 * q2);
+  } else {
+    const double e0 = 1.0e-6 + b0, e1 = 1.0e-6 + b1, e2 = 1.0e-6 + b2;
+    n0 = k.lw0 / (e0 * e0);
+    n1 = k.lw1 / (e1 * e1);
+    n2 = k.lw2 / (e2 * e2);
+  }
+  const double inv = 1.0 / (n0 + n1 + n2);
+  return (n0 * s0 + n1 * s1 + n2 * s2) * inv;
+}
+
+// ---- inviscid fluxes --------------------------------------------------------
+// inviscidFlux::ConstructFromPrim inviscidFlux.hpp:129-160
+__device__ __forceinline__ void phys_flux(const GasDev& g, const double* s,
+                                          const double* n, double* f) {
+  const double vn = dot3(s + 1, n);
+  const double m = s[0] * vn;
+  f[0] = m;
+  f[1] = m * s[1] + s[4] * n[0];
+  f[2] = m * s[2] + s[4] * n[1];
+  f[3] = m * s[3] + s[4] * n[2];
+  f[4] = m * enthalpy(g, s);
+}
+
+// RoeFlux inviscidFlux.hpp:260-382 with RoeAveragedState primitive.hpp:245-280
+// (pressure is Roe-averaged, enthalpy derived from it) and Harten's fix 0.1
+__device__ __forceinline__ void roe_flux(const GasDev& g, const double* l,
+                                         const double* r, const double* n,
+                                         double* flux) {
+  double roe[AGX_NEQ];
+  const double dr = sqrt(r[0] / l[0]);
+  const double inv1 = 1.0 / (1.0 + dr);
+  roe[0] = l[0] * dr;
+#pragma unroll
+  for (int e = 1; e < AGX_NEQ; ++e) roe[e] = (l[e] + dr * r[e]) * inv1;
+  const double hR = enthalpy(g, roe);
+  const double aR = sound_speed(g, roe);
+  const double rhoR = roe[0];
+  const double vnR = dot3(roe + 1, n);
+  double d[AGX_NEQ];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) d[e] = r[e] - l[e];
+  const double dvn = dot3(d + 1, n);
+  const double fix = 0.1;
+  const double inv_a2 = 1.0 / (aR * aR);
+  double diss[AGX_NEQ];
+  // left acoustic
+  double ws = fabs(vnR - aR);
+  if (ws < fix) ws = 0.5 * (ws * ws / fix + fix);
+  double wss = ws * (d[4] - rhoR * aR * dvn) * 0.5 * inv_a2;
+  diss[0] = wss;
+  diss[1] = wss * (roe[1] - aR * n[0]);
+  diss[2] = wss * (roe[2] - aR * n[1]);
+  diss[3] = wss * (roe[3] - aR * n[2]);
+  diss[4] = wss * (hR - aR * vnR);
+  // entropy
+  ws = fabs(vnR);
+  diss[0] += ws * (-d[4] * inv_a2) + ws * d[0];
+  wss = ws * (d[0] - d[4] * inv_a2);
+  diss[1] += wss * roe[1];
+  diss[2] += wss * roe[2];
+  diss[3] += wss * roe[3];
+  diss[4] += wss * 0.5 * dot3(roe + 1, roe + 1);
+  // shear
+  wss = ws * rhoR;
+  diss[1] += wss * (d[1] - dvn * n[0]);
+  diss[2] += wss * (d[2] - dvn * n[1]);
+  diss[3] += wss * (d[3] - dvn * n[2]);
+  diss[4] += wss * (dot3(roe + 1, d + 1) - vnR * dvn);
+  // right acoustic
+  ws = fabs(vnR + aR);
+  if (ws < fix) ws = 0.5 * (ws * ws / fix + fix);
+  wss = ws * (d[4] + rhoR * aR * dvn) * 0.5 * inv_a2;
+  diss[0] += wss;
+  diss[1] += wss * (roe[1] + aR * n[0]);
+  diss[2] += wss * (roe[2] + aR * n[1]);
+  diss[3] += wss * (roe[3] + aR * n[2]);
+  diss[4] += wss * (hR + aR * vnR);
+  double fl[AGX_NEQ], fr[AGX_NEQ];
+  phys_flux(g, l, n, fl);
+  phys_flux(g, r, n, fr);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) flux[e] = 0.5 * (fl[e] + fr[e] - diss[e]);
+}
+
+// AUSMFlux (AUSMPW+) inviscidFlux.hpp:396-481 and member :162-209
+__device__ __forceinline__ void ausm_flux(const GasDev& g, const double* l,
+                                          const double* r, const double* n,
+                                          double* f) {
+  const double vnL = dot3(l + 1, n), vnR = dot3(r + 1, n);
+  const double cS = sqrt(sound_speed(g, l) * sound_speed(g, r));
+  const double vel = 0.5 * (vnL + vnR);
+  double c = cS;
+  if (vel < 0.0) c = cS * cS / fmax(vnR, cS);
+  else if (vel > 0.0) c = cS * cS / fmax(vnL, cS);
+  const double ml = vnL / c, mr = vnR / c;
+  const double sl = (ml > 0.0) - (ml < 0.0), sr = (mr > 0.0) - (mr < 0.0);
+  const bool subl = fabs(ml) <= 1.0, subr = fabs(mr) <= 1.0;
+  const double mPlusL = subl ? 0.25 * (ml + 1.0) * (ml + 1.0) : 0.5 * (ml + fabs(ml));
+  const double mMinusR = subr ? -0.25 * (mr - 1.0) * (mr - 1.0) : 0.5 * (mr - fabs(mr));
+  const double pPlus = subl ? 0.25 * (ml + 1.0) * (ml + 1.0) * (2.0 - ml) : 0.5 * (1.0 + sl);
+  const double pMinus = subr ? 0.25 * (mr - 1.0) * (mr - 1.0) * (2.0 + mr) : 0.5 * (1.0 - sr);
+  const double ps = pPlus * l[4] + pMinus * r[4];
+  const double pm = fmin(l[4] / r[4], r[4] / l[4]);
+  const double w = 1.0 - pm * pm * pm;
+  const double fl = fabs(ml) < 1.0 ? l[4] / ps - 1.0 : 0.0;
+  const double fr = fabs(mr) < 1.0 ? r[4] / ps - 1.0 : 0.0;
+  const double mavg = mPlusL + mMinusR;
+  const double mPlusLBar = mavg >= 0.0
+      ? mPlusL + mMinusR * ((1.0 - w) * (1.0 + fr) - fl) : mPlusL * w * (1.0 + fl);
+  const double mMinusRBar = mavg >= 0.0
+      ? mMinusR * w * (1.0 + fr) : mMinusR + mPlusL * ((1.0 - w) * (1.0 + fl) - fr);
+  const double vl = mPlusLBar * c, vr = mMinusRBar * c;
+  const double ml_ = l[0] * vl, mr_ = r[0] * vr;
+  f[0] = ml_ + mr_;
+  const double pf = pPlus * l[4] + pMinus * r[4];
+  f[1] = ml_ * l[1] + mr_ * r[1] + pf * n[0];
+  f[2] = ml_ * l[2] + mr_ * r[2] + pf * n[1];
+  f[3] = ml_ * l[3] + mr_ * r[3] + pf * n[2];
+  f[4] = ml_ * enthalpy(g, l) + mr_ * enthalpy(g, r);
+}
+
+template <int FLUX>
+__device__ __forceinline__ void inviscid_flux(const GasDev& g, const double* l,
+                                              const double* r, const double* n,
+                                              double* f) {
+  if (FLUX == AGX_FLUX_ROE) roe_flux(g, l, r, n, f);
+  else ausm_flux(g, l, r, n, f);
+}
+
+// InvCellSpectralRadius spectralRadius.hpp:44-64; al/au = {nx,ny,nz,|A|}
+__device__ __forceinline__ double inv_cell_spec_rad(const GasDev& g,
+                                                    const double* s,
+                                                    const double* al,
+                                                    const double* au) {
+  double v[3] = {0.5 * (al[0] + au[0]), 0.5 * (al[1] + au[1]),
+                 0.5 * (al[2] + au[2])};
+  const double im = 1.0 / sqrt(dot3(v, v));
+  const double fmag = 0.5 * (al[3] + au[3]);
+  return (fabs(dot3(s + 1, v)) * im + sound_speed(g, s)) * fmag;
+}
+// viscous term of ViscCell/FaceSpectralRadius spectralRadius.hpp:94-160
+__device__ __forceinline__ double visc_max_term(const GasDev& g, double rho) {
+  return fmax(4.0 / (3.0 * rho), g.gamma / rho);
+}
+__device__ __forceinline__ double visc_term(const GasDev& g, double mu) {
+  return g.scaling * (mu / g.prandtl);
+}
+
+// RusanovScalarOffDiagonal fluxJacobian.cpp:122-162 with FaceSpectralRadius
+// spectralRadius.hpp:182-203 and ConvectiveFluxUpdate inviscidFlux.hpp:544-562
+__device__ __forceinline__ void off_diagonal(const GasDev& g, bool viscous,
+                                             const double* s, const double* du,
+                                             const double* area, double mu,
+                                             double dist, bool positive,
+                                             double* out) {
+  double su[AGX_NEQ], fo[AGX_NEQ], fn[AGX_NEQ];
+  update_prim_with_cons(g, s, du, su);
+  phys_flux(g, s, area, fo);
+  phys_flux(g, su, area, fn);
+  double sr = 0.5 * area[3] * (fabs(dot3(s + 1, area)) + sound_speed(g, s));
+  if (viscous) sr += area[3] / dist * visc_max_term(g, s[0]) * visc_term(g, mu);
+  const double sg = positive ? 1.0 : -1.0;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e)
+    out[e] = 0.5 * area[3] * (fn[e] - fo[e]) + sg * du[e] * sr;
+}
+
+// ---- ghost states, ghostStates.cpp:62-708 ----------------------------------
+__device__ __forceinline__ void extrap_hold(const double* bnd, double factor,
+                                            const double* in, double* out) {
+  // ExtrapolateHoldMixture ghostStates.cpp:691-708
+  const double grho = factor * bnd[0] - in[0];
+  if (grho <= 0.0) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) out[e] = bnd[e];
+    return;
+  }
+  double t[AGX_NEQ];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) t[e] = factor * bnd[e] - in[e];
+  t[0] = fmax(grho, 0.0);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) out[e] = t[e];
+}
+
+// GetGhostState; returns false for a BC variant this build does not cover
+__device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
+                                   const double* area_unit, int surf,
+                                   const agx_bc_state& d, int layer,
+                                   double* gh) {
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) gh[e] = in[e];
+  const double sgn = (surf % 2 == 1) ? -1.0 : 1.0;
+  const double n[3] = {sgn * area_unit[0], sgn * area_unit[1], sgn * area_unit[2]};
+  switch (bc) {
+    case AGX_BC_SLIPWALL: {
+      const double vn = dot3(in + 1, n);
+      for (int q = 0; q < 3; ++q) gh[1 + q] = in[1 + q] - 2.0 * n[q] * vn;
+      return true;
+    }
+    case AGX_BC_VISCOUSWALL: {
+      for (int q = 0; q < 3; ++q) gh[1 + q] = 2.0 * d.velocity[q] - in[1 + q];
+      if (d.is_isothermal) {
+        const double tg = 2.0 * d.wall_temperature - temperature(g, in);
+        gh[0] = gh[4] / (g.R * tg);
+      } else if (d.is_heat_flux) {
+        return false;
+      }
+      return true;
+    }
+    case AGX_BC_CHARACTERISTIC:
+    case AGX_BC_INLET: {
+      if (bc == AGX_BC_INLET && d.is_nonreflecting) return false;
+      const double fs[AGX_NEQ] = {d.density, d.velocity[0], d.velocity[1],
+                                  d.velocity[2], d.pressure};
+      const double vn = dot3(in + 1, n);
+      const double c = sound_speed(g, in);
+      const double mach = fabs(vn) / c;
+      const bool inflow = vn < 0.0;
+      bool extrap = true;
+      if (mach >= 1.0 && (inflow || bc == AGX_BC_INLET)) {
+        for (int e = 0; e < AGX_NEQ; ++e) gh[e] = fs[e];
+        if (bc == AGX_BC_INLET) extrap = false;   // ghostStates.cpp:412-424
+      } else if (mach >= 1.0) {
+        // supersonic outflow: interior
+      } else if (inflow || bc == AGX_BC_INLET) {
+        const double rc = in[0] * c;
+        const double vd[3] = {fs[1] - in[1], fs[2] - in[2], fs[3] - in[3]};
+        gh[4] = 0.5 * (fs[4] + in[4] - rc * dot3(n, vd));
+        const double dp = fs[4] - gh[4];
+        gh[0] = fs[0] - dp / (c * c);
+        for (int q = 0; q < 3; ++q) gh[1 + q] = fs[1 + q] - n[q] * dp / rc;
+      } else {
+        const double rc = in[0] * c;
+        const double dp = in[4] - fs[4];
+        gh[0] = in[0] - dp / (c * c);
+        for (int q = 0; q < 3; ++q) gh[1 + q] = in[1 + q] + n[q] * dp / rc;
+        gh[4] = fs[4];
+      }
+      if (extrap) {
+        double t[AGX_NEQ];
+        extrap_hold(gh, 2.0, in, t);
+        for (int e = 0; e < AGX_NEQ; ++e) gh[e] = t[e];
+        if (layer > 1) {
+          extrap_hold(gh, (double)layer, in, t);
+          for (int e = 0; e < AGX_NEQ; ++e) gh[e] = t[e];
+        }
+      }
+      return true;
+    }
+    case AGX_BC_SUPERSONIC_INFLOW:
+      gh[0] = d.density; gh[1] = d.velocity[0]; gh[2] = d.velocity[1];
+      gh[3] = d.velocity[2]; gh[4] = d.pressure;
+      return true;
+    case AGX_BC_SUPERSONIC_OUTFLOW:
+      if (layer > 1)
+        for (int e = 0; e < AGX_NEQ; ++e) gh[e] = layer * gh[e] - in[e];
+      return true;
+    case AGX_BC_STAGNATION_INLET: {
+      const double gm1 = g.gamma - 1.0;
+      const double c = sound_speed(g, in);
+      const double vn = dot3(in + 1, n);
+      const double v2 = dot3(in + 1, in + 1);
+      const double rneg = vn - 2.0 * c / gm1;
+      const double ct = -vn / sqrt(v2);
+      const double c0sq = c * c + 0.5 * gm1 * v2;
+      const double k = gm1 * ct * ct + 2.0;
+      const double cb = -rneg * gm1 / k *
+          (1.0 + ct * sqrt(k * c0sq / (gm1 * rneg * rneg) - 0.5 * gm1));
+      const double ratio = cb * cb / c0sq;
+      const double tb = d.stagnation_temperature * ratio;
+      const double pb = d.stagnation_pressure * pow(ratio, g.gamma / gm1);
+      const double vb = sqrt(2.0 / gm1 * (d.stagnation_temperature - tb));
+      gh[0] = pb / (g.R * tb);
+      gh[1] = vb * d.direction[0];
+      gh[2] = vb * d.direction[1];
+      gh[3] = vb * d.direction[2];
+      gh[4] = pb;
+      double t[AGX_NEQ];
+      extrap_hold(gh, 2.0, in, t);
+      for (int e = 0; e < AGX_NEQ; ++e) gh[e] = t[e];
+      if (layer > 1) {
+        extrap_hold(gh, (double)layer, in, t);
+        for (int e = 0; e < AGX_NEQ; ++e) gh[e] = t[e];
+      }
+      return true;
+    }
+    case AGX_BC_PRESSURE_OUTLET: {
+      if (d.is_nonreflecting) return false;
+      const double c = sound_speed(g, in);
+      const double rc = in[0] * c;
+      gh[4] = d.pressure;
+      const double dp = in[4] - gh[4];
+      gh[0] = in[0] - dp / (c * c);
+      for (int q = 0; q < 3; ++q) gh[1 + q] = in[1 + q] + n[q] * dp / rc;
+      if (dot3(gh + 1, n) / sound_speed(g, gh) >= 1.0)
+        for (int e = 0; e < AGX_NEQ; ++e) gh[e] = in[e];
+      for (int e = 0; e < AGX_NEQ; ++e) gh[e] = 2.0 * gh[e] - in[e];
+      if (layer > 1)
+        for (int e = 0; e < AGX_NEQ; ++e) gh[e] = layer * gh[e] - in[e];
+      return true;
+    }
+    case AGX_BC_INTERBLOCK:
+    case AGX_BC_PERIODIC:
+      return true;
+  }
+  return false;
+}
+
+}  // namespace agx

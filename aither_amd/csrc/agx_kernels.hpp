@@ -1,0 +1,808 @@
+// agx_kernels.hpp -- HIP kernels of the hot path (gfx950, wave64, fp64).
+//
+// Data layout in HBM: structure of arrays.  Every per-cell and per-face
+// quantity of a block is a separate plane of doubles with ONE common padded
+// indexing
+//     q(i,j,k) = (k+ng)*sxy + (j+ng)*sx + (i+ioff)
+// where ioff >= ng is chosen so that physical cell i = 0 starts a 128-byte
+// line, sx is a multiple of 16 doubles and face (i,j,k) of direction d is the
+// LOWER d-face of cell (i,j,k).  Consecutive lanes of a wavefront walk
+// consecutive i => every load/store of a plane is a fully coalesced 512-byte
+// request per wave.  (The reference's AoS multiArray3d, multiArray3d.hpp:104-113,
+// is converted at upload/download only.)
+#pragma once
+#include "agx_device.hpp"
+
+namespace agx {
+
+struct BlockDev {
+  int ni, nj, nk, ng;
+  int ioff;
+  long sx, sxy, nplane;       // strides and plane length
+  int parent;
+  double* state[AGX_NEQ];     // state_                  procBlock.hpp:65
+  double* fa[3][4];           // fAreaI/J/K_ {nx,ny,nz,|A|}   :71-73
+  double* vol;                // vol_                    :81
+  double* cen[3];             // center_                 :82
+  double* wid[3];             // cellWidthI/J/K_         :84-86
+  double* resid[AGX_NEQ];     // residual_               :68
+  double* specrad;            // specRadius_ (flow)      :74
+  double* dt;                 // dt_                     :76
+  double* consn[AGX_NEQ];     // consVarsN_              :66
+  double* consnm1[AGX_NEQ];   // consVarsNm1_            :67
+  double* x[AGX_NEQ];         // linearSolver::x_        linearSolver.hpp:38
+  double* xold[AGX_NEQ];      // dplur copy              linearSolver.cpp:487
+  double* a;                  // linearSolver::a_ (scalar flow part)
+  double* ainv;               // linearSolver::aInv_
+  const agx_bc_surface* surf; // boundaryConditions      boundaryConditions.hpp:231
+  int nsurf, nsurf_i, nsurf_j, nsurf_k;
+  __host__ __device__ long idx(int i, int j, int k) const {
+    return (long)(k + ng) * sxy + (long)(j + ng) * sx + (i + ioff);
+  }
+  __host__ __device__ long stride(int d) const {
+    return d == 0 ? 1 : (d == 1 ? sx : sxy);
+  }
+};
+
+struct SolverDev {   // scalar run-time parameters of agx_config
+  double kappa, theta, zeta, relax, dual_time_cfl, dt_fixed, visc_cfl_coeff;
+  int viscous, implicit, bdf2, requires_init, time_integration;
+};
+
+__device__ __forceinline__ void load5(double* const* p, long q, double* s) {
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) s[e] = p[e][q];
+}
+__device__ __forceinline__ void store5(double* const* p, long q, const double* s) {
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) p[e][q] = s[e];
+}
+__device__ __forceinline__ void load_area(const BlockDev& b, int d, long q, double* a) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) a[c] = b.fa[d][c][q];
+}
+
+// ---------------------------------------------------------------------------
+// Inviscid residual, one thread per cell (gather form): the six face fluxes
+// are added to the cell in the reference's order (-I_lower, +I_upper,
+// -J_lower, +J_upper, -K_lower, +K_upper; procBlock.cpp:447-463,6121-6123),
+// so no atomics and a reproducible sum.  Also forms the inviscid cell
+// spectral radius, the scalar implicit diagonal and (inviscid runs) dt.
+// Counterpart of procBlock::CalcInvFluxI/J/K procBlock.cpp:384-795.
+template <int RECON, int LIM, int FLUX>
+__device__ __forceinline__ void face_flux_1d(const GasDev& g, double kappa,
+                                             const double (*st)[AGX_NEQ],
+                                             const double* w, int c,
+                                             const double* area, double* f) {
+  // st[m], w[m]: 1-D stencil; the face lies between entries c-1 and c
+  double l[AGX_NEQ], r[AGX_NEQ];
+  if (RECON == AGX_RECON_CONSTANT) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) { l[e] = st[c - 1][e]; r[e] = st[c][e]; }
+  } else if (RECON == AGX_RECON_MUSCL) {
+    // FaceReconMUSCL reconstruction.hpp:110-154
+    const double dPl = (w[c - 1] + w[c - 1]) / (w[c - 1] + w[c]);
+    const double dMl = (w[c - 1] + w[c - 1]) / (w[c - 1] + w[c - 2]);
+    const double dPr = (w[c] + w[c]) / (w[c] + w[c - 1]);
+    const double dMr = (w[c] + w[c]) / (w[c] + w[c + 1]);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      l[e] = muscl<LIM>(st[c - 2][e], st[c - 1][e], st[c][e], dPl, dMl, kappa);
+      r[e] = muscl<LIM>(st[c + 1][e], st[c][e], st[c - 1][e], dPr, dMr, kappa);
+    }
+  } else {
+    // FaceReconWENO reconstruction.hpp:244-310
+    const double cwl[5] = {w[c - 3], w[c - 2], w[c - 1], w[c], w[c + 1]};
+    const double cwr[5] = {w[c + 2], w[c + 1], w[c], w[c - 1], w[c - 2]};
+    WenoCoeffs kl, kr;
+    weno_coeffs(cwl, kl);
+    weno_coeffs(cwr, kr);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      l[e] = weno<RECON == AGX_RECON_WENOZ>(kl, cwl, st[c - 3][e], st[c - 2][e],
+                                            st[c - 1][e], st[c][e], st[c + 1][e]);
+      r[e] = weno<RECON == AGX_RECON_WENOZ>(kr, cwr, st[c + 2][e], st[c + 1][e],
+                                            st[c][e], st[c - 1][e], st[c - 2][e]);
+    }
+  }
+  inviscid_flux<FLUX>(g, l, r, area, f);
+}
+
+template <int RECON, int LIM, int FLUX>
+__global__ void __launch_bounds__(256)
+k_inv_residual(BlockDev b, GasDev g, SolverDev sp, double cfl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  constexpr int H = RECON == AGX_RECON_CONSTANT ? 1
+                    : (RECON == AGX_RECON_MUSCL ? 2 : 3);
+  constexpr int NS = 2 * H + 1;
+  const long q = b.idx(i, j, k);
+  double res[AGX_NEQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  double sr = 0.0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const long s = b.stride(d);
+    double st[NS][AGX_NEQ], w[NS];
+#pragma unroll
+    for (int m = 0; m < NS; ++m) {
+      const long qq = q + (m - H) * s;
+      load5(b.state, qq, st[m]);
+      w[m] = b.wid[d][qq];
+    }
+    double al[4], au[4], f[AGX_NEQ];
+    load_area(b, d, q, al);
+    load_area(b, d, q + s, au);
+    face_flux_1d<RECON, LIM, FLUX>(g, sp.kappa, st, w, H, al, f);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) res[e] -= f[e] * al[3];
+    face_flux_1d<RECON, LIM, FLUX>(g, sp.kappa, st, w, H + 1, au, f);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) res[e] += f[e] * au[3];
+    sr += inv_cell_spec_rad(g, st[H], al, au);
+  }
+  store5(b.resid, q, res);
+  b.specrad[q] = sr;
+  if (sp.implicit) b.a[q] = sr;
+  if (!sp.viscous)
+    b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (b.vol[q] / fmax(sr, 0.0));
+}
+
+// ---------------------------------------------------------------------------
+// Viscous residual, one thread per cell, six faces.  Counterpart of
+// procBlock::CalcViscFluxI/J/K procBlock.cpp:1233-2135 (laminar, central
+// reconstruction) with CalcGradsI/J/K :5173-5786, VectorGradGG/ScalarGradGG
+// utility.cpp:59-188, viscousFlux::CalcFlux viscousFlux.cpp:58-135 and
+// TauNormal utility.cpp:426-437.  Temperature and viscosity are recomputed
+// from the state (UpdateAuxillaryVariables procBlock.cpp:6171) -- no arrays.
+__device__ __forceinline__ void area_vec(const BlockDev& b, int d, long q, double* v) {
+  const double m = b.fa[d][3][q];
+  v[0] = b.fa[d][0][q] * m; v[1] = b.fa[d][1][q] * m; v[2] = b.fa[d][2][q] * m;
+}
+__device__ __forceinline__ void uvwt(const BlockDev& b, const GasDev& g, long q, double* v) {
+  const double rho = b.state[0][q];
+  v[0] = b.state[1][q]; v[1] = b.state[2][q]; v[2] = b.state[3][q];
+  v[3] = b.state[4][q] / (rho * g.R);
+}
+// viscous flux * |A| through the lower d-face of cell index qU (cells qL|qU)
+__device__ __forceinline__ void visc_face(const BlockDev& b, const GasDev& g,
+                                          int d, long qU, double* f) {
+  const long sd = b.stride(d);
+  const long qL = qU - sd;
+  double grad[3][4];          // [derivative direction][u, v, w, T]
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) grad[r][c] = 0.0;
+  double vL[4], vU[4];
+  uvwt(b, g, qL, vL);
+  uvwt(b, g, qU, vU);
+  {
+    double a0[3], a1[3], a2[3];
+    area_vec(b, d, qU, a0);
+    area_vec(b, d, qU + sd, a1);
+    area_vec(b, d, qU - sd, a2);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double au = 0.5 * (a0[r] + a1[r]), al = 0.5 * (a0[r] + a2[r]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) grad[r][c] += vU[c] * au - vL[c] * al;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    if (t == d) continue;
+    const long stt = b.stride(t);
+    double a0[3], a1[3], vu[4], vl[4], t0[4], t1[4];
+    area_vec(b, t, qU + stt, a0);
+    area_vec(b, t, qL + stt, a1);
+    uvwt(b, g, qU + stt, t0);
+    uvwt(b, g, qL + stt, t1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vu[c] = 0.25 * (vL[c] + vU[c] + t0[c] + t1[c]);
+    double b0[3], b1[3];
+    area_vec(b, t, qU, b0);
+    area_vec(b, t, qL, b1);
+    uvwt(b, g, qU - stt, t0);
+    uvwt(b, g, qL - stt, t1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vl[c] = 0.25 * (vL[c] + vU[c] + t0[c] + t1[c]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double au = 0.5 * (a0[r] + a1[r]), al = 0.5 * (b0[r] + b1[r]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) grad[r][c] += vu[c] * au - vl[c] * al;
+    }
+  }
+  const double inv_vol = 1.0 / (0.5 * (b.vol[qL] + b.vol[qU]));
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) grad[r][c] *= inv_vol;
+  // FaceReconCentral reconstruction.hpp:315-328: coeffs = LagrangeCoeff(
+  // {wU, wD}, 1, 0, 0) = {wD, wU} / (wU + wD) and the reference forms
+  // coeffs[0] * varD + coeffs[1] * varU (the wider cell gets the larger weight)
+  const double wU = b.wid[d][qL], wD = b.wid[d][qU];
+  const double cD = wD / (wU + wD), cU = wU / (wU + wD);
+  double sL[AGX_NEQ], sU[AGX_NEQ], sf[AGX_NEQ];
+  load5(b.state, qL, sL);
+  load5(b.state, qU, sU);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) sf[e] = cD * sU[e] + cU * sL[e];
+  const double muf = cD * viscosity(g, vU[3]) + cU * viscosity(g, vL[3]);
+  double n[4];
+  load_area(b, d, qU, n);
+  const double mu = g.scaling * muf;
+  const double lambda = -(2.0 / 3.0) * mu;
+  const double trace = grad[0][0] + grad[1][1] + grad[2][2];
+  double tau[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double mm = (grad[r][0] + grad[0][r]) * n[0] +
+                      (grad[r][1] + grad[1][r]) * n[1] +
+                      (grad[r][2] + grad[2][r]) * n[2];
+    tau[r] = lambda * trace * n[r] + mu * mm;
+  }
+  const double kk = conductivity(g, temperature(g, sf)) * g.scaling;
+  const double tg = grad[0][3] * n[0] + grad[1][3] * n[1] + grad[2][3] * n[2];
+  f[0] = 0.0;
+  f[1] = tau[0] * n[3];
+  f[2] = tau[1] * n[3];
+  f[3] = tau[2] * n[3];
+  f[4] = (dot3(tau, sf + 1) + kk * tg) * n[3];
+}
+
+__global__ void __launch_bounds__(256)
+k_visc_residual(BlockDev b, GasDev g, SolverDev sp, double cfl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  double res[AGX_NEQ];
+  load5(b.resid, q, res);
+  double sr = b.specrad[q];
+  double diag = sp.implicit ? b.a[q] : 0.0;
+  double sc[AGX_NEQ];
+  load5(b.state, q, sc);
+  const double muc = viscosity(g, temperature(g, sc));
+  const double vol = b.vol[q];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const long s = b.stride(d);
+    double f[AGX_NEQ];
+    visc_face(b, g, d, q, f);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) res[e] += f[e];
+    visc_face(b, g, d, q + s, f);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) res[e] -= f[e];
+    // ViscCellSpectralRadius spectralRadius.hpp:94-124
+    const double fmag = 0.5 * (b.fa[d][3][q] + b.fa[d][3][q + s]);
+    const double vsr = visc_max_term(g, sc[0]) * visc_term(g, muc) * fmag * fmag / vol;
+    sr += vsr * sp.visc_cfl_coeff;
+    diag += 2.0 * vsr;
+  }
+  store5(b.resid, q, res);
+  b.specrad[q] = sr;
+  if (sp.implicit) b.a[q] = diag;
+  b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (vol / fmax(sr, 0.0));
+}
+
+// ---------------------------------------------------------------------------
+// boundary conditions
+// boundaryConditions::GetBCSurface boundaryConditions.cpp:109-170
+__device__ inline const agx_bc_surface* get_bc_surface(const BlockDev& b, int i,
+                                                       int j, int k, int surf) {
+  if (surf <= 2) {
+    for (int n = 0; n < b.nsurf_i; ++n) {
+      const agx_bc_surface* s = b.surf + n;
+      if (i >= s->imin && i <= s->imax && j >= s->jmin && j < s->jmax &&
+          k >= s->kmin && k < s->kmax) return s;
+    }
+  } else if (surf <= 4) {
+    for (int n = b.nsurf_i; n < b.nsurf_i + b.nsurf_j; ++n) {
+      const agx_bc_surface* s = b.surf + n;
+      if (i >= s->imin && i < s->imax && j >= s->jmin && j <= s->jmax &&
+          k >= s->kmin && k < s->kmax) return s;
+    }
+  } else {
+    for (int n = b.nsurf_i + b.nsurf_j; n < b.nsurf; ++n) {
+      const agx_bc_surface* s = b.surf + n;
+      if (i >= s->imin && i < s->imax && j >= s->jmin && j < s->jmax &&
+          k >= s->kmin && k <= s->kmax) return s;
+    }
+  }
+  return nullptr;
+}
+__device__ __forceinline__ bool bc_is_connection(const BlockDev& b, int i, int j,
+                                                 int k, int surf) {
+  const agx_bc_surface* s = get_bc_surface(b, i, j, k, surf);
+  return s && (s->bc_type == AGX_BC_INTERBLOCK || s->bc_type == AGX_BC_PERIODIC);
+}
+__host__ __device__ inline int surface_type(const agx_bc_surface& s) {
+  if (s.imin == s.imax) return s.imax == 0 ? 1 : 2;
+  if (s.jmin == s.jmax) return s.jmax == 0 ? 3 : 4;
+  return s.kmax == 0 ? 5 : 6;
+}
+
+// Face ghost cells of ONE surface: procBlock::AssignInviscidGhostCells
+// procBlock.cpp:2449-2532 (viscous = 0) / AssignViscousGhostCells :2760-2838
+// (viscous = 1, viscousWall surfaces only).  All layers and surfaces are
+// independent (they read physical cells only), so they run concurrently.
+__global__ void k_bc_faces(BlockDev b, GasDev g, int sn, int viscous, int* err) {
+  const agx_bc_surface sf = b.surf[sn];
+  const int st = surface_type(sf);
+  const int d3 = (st - 1) / 2, d1 = (d3 + 1) % 3, d2 = (d3 + 2) % 3;
+  const int lo[3] = {sf.imin, sf.jmin, sf.kmin}, hi[3] = {sf.imax, sf.jmax, sf.kmax};
+  const int n1 = hi[d1] - lo[d1], n2 = hi[d2] - lo[d2];
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n1 * n2 * b.ng) return;
+  const int layer = (int)(t / ((long)n1 * n2)) + 1;
+  const int rem = (int)(t % ((long)n1 * n2));
+  // the fastest-varying surface direction gets consecutive lanes
+  int a1, a2;
+  if (d1 < d2) { a1 = lo[d1] + rem % n1; a2 = lo[d2] + rem / n1; }
+  else { a2 = lo[d2] + rem % n2; a1 = lo[d1] + rem / n2; }
+  const int nn[3] = {b.ni, b.nj, b.nk};
+  const int r3 = lo[d3];
+  int gCell, iCell, aCell;
+  if (st % 2 == 0) {
+    gCell = r3 + layer - 1; iCell = max(r3 - layer, 0); aCell = r3 - 1;
+  } else {
+    gCell = r3 - layer; iCell = min(r3 + layer - 1, nn[d3] - 1); aCell = r3;
+  }
+  int bc = sf.bc_type;
+  if (bc == AGX_BC_INTERBLOCK || bc == AGX_BC_PERIODIC) return;
+  if (viscous) { if (bc != AGX_BC_VISCOUSWALL) return; }
+  else if (bc == AGX_BC_VISCOUSWALL) bc = AGX_BC_SLIPWALL;
+  const int src = (bc == AGX_BC_SLIPWALL || viscous) ? iCell : aCell;
+  int c[3];
+  c[d1] = a1; c[d2] = a2;
+  c[d3] = src;   const long qs = b.idx(c[0], c[1], c[2]);
+  c[d3] = gCell; const long qg = b.idx(c[0], c[1], c[2]);
+  c[d3] = r3;    const long qf = b.idx(c[0], c[1], c[2]);
+  double in[AGX_NEQ], gh[AGX_NEQ], area[4];
+  load5(b.state, qs, in);
+  load_area(b, d3, qf, area);
+  if (!ghost_state(g, in, bc, area, st, sf.state, layer, gh)) { *err = 1; return; }
+  store5(b.state, qg, gh);
+}
+
+// Edge ghost cells: procBlock::AssignInviscidGhostCellsEdge procBlock.cpp:2565-2708
+// and AssignViscousGhostCellsEdge :2874-3029.  One thread per (edge, d1); the
+// ng x ng layer recursion is serial inside the thread (each layer reads the
+// previous one of the same d1 only).
+__global__ void k_bc_edges(BlockDev b, GasDev g, int viscous, int* err) {
+  const int nn[3] = {b.ni, b.nj, b.nk};
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int dd = -1, cc = 0, d1 = 0;
+  for (int q = 0; q < 3; ++q) {
+    if (t < 4L * nn[q]) { dd = q; cc = (int)(t / nn[q]); d1 = (int)(t % nn[q]); break; }
+    t -= 4L * nn[q];
+  }
+  if (dd < 0) return;
+  const int e2 = (dd + 1) % 3, e3 = (dd + 2) % 3;
+  const int max2 = nn[e2], max3 = nn[e3];
+  const bool upper2 = cc > 1, upper3 = cc % 2 == 1;
+  const int surf2 = 2 * e2 + 1 + (upper2 ? 1 : 0), surf3 = 2 * e3 + 1 + (upper3 ? 1 : 0);
+  const int cF22 = upper2 ? max2 : 0, cF23 = upper3 ? max3 - 1 : 0;
+  const int cF32 = upper2 ? max2 - 1 : 0, cF33 = upper3 ? max3 : 0;
+  int c[3];
+  c[dd] = d1; c[e2] = cF22; c[e3] = cF23;
+  const agx_bc_surface* s2 = get_bc_surface(b, c[0], c[1], c[2], surf2);
+  c[e2] = cF32; c[e3] = cF33;
+  const agx_bc_surface* s3 = get_bc_surface(b, c[0], c[1], c[2], surf3);
+  int bc2 = s2 ? s2->bc_type : -1, bc3 = s3 ? s3->bc_type : -1;
+  if (!viscous) {
+    if (bc2 == AGX_BC_VISCOUSWALL) bc2 = AGX_BC_SLIPWALL;
+    if (bc3 == AGX_BC_VISCOUSWALL) bc3 = AGX_BC_SLIPWALL;
+  }
+  for (int layer3 = 1; layer3 <= b.ng; ++layer3)
+    for (int layer2 = 1; layer2 <= b.ng; ++layer2) {
+      const int p2 = upper2 ? max2 + layer2 - 2 : 1 - layer2;
+      const int g2 = upper2 ? p2 + 1 : p2 - 1;
+      const int p3 = upper3 ? max3 + layer3 - 2 : 1 - layer3;
+      const int g3 = upper3 ? p3 + 1 : p3 - 1;
+      c[e2] = p2; c[e3] = g3; const long qP2 = b.idx(c[0], c[1], c[2]);
+      c[e2] = g2; c[e3] = p3; const long qP3 = b.idx(c[0], c[1], c[2]);
+      c[e2] = g2; c[e3] = g3; const long qG = b.idx(c[0], c[1], c[2]);
+      double gh[AGX_NEQ], in[AGX_NEQ], area[4];
+      if (bc2 == AGX_BC_SLIPWALL && bc3 != AGX_BC_SLIPWALL) {
+        c[e2] = cF22; c[e3] = g3;
+        load_area(b, e2, b.idx(c[0], c[1], c[2]), area);
+        load5(b.state, qP2, in);
+        if (!ghost_state(g, in, bc2, area, surf2, s2->state, layer2, gh)) { *err = 1; return; }
+        store5(b.state, qG, gh);
+      } else if (bc2 != AGX_BC_SLIPWALL && bc3 == AGX_BC_SLIPWALL) {
+        c[e2] = g2; c[e3] = cF33;
+        load_area(b, e3, b.idx(c[0], c[1], c[2]), area);
+        load5(b.state, qP3, in);
+        if (!ghost_state(g, in, bc3, area, surf3, s3->state, layer3, gh)) { *err = 1; return; }
+        store5(b.state, qG, gh);
+      } else if (!viscous || (bc2 == AGX_BC_VISCOUSWALL && bc3 == AGX_BC_VISCOUSWALL)) {
+        if (layer2 == layer3) {
+          double a[AGX_NEQ];
+          load5(b.state, qP2, in);
+          load5(b.state, qP3, a);
+          for (int e = 0; e < AGX_NEQ; ++e) gh[e] = 0.5 * (in[e] + a[e]);
+        } else if (layer2 > layer3) {
+          load5(b.state, qP3, gh);
+        } else {
+          load5(b.state, qP2, gh);
+        }
+        store5(b.state, qG, gh);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// halo exchange: multiArray3d.hpp:790-918 (SwapSliceLocal / InsertSlice) with
+// index maps precomputed on the host from GetSwapLoc
+// (boundaryConditions.cpp:3006-3181).  buf is [n][ncomp].
+struct Planes5 { double* p[AGX_NEQ]; };
+__global__ void k_halo_gather(Planes5 a, const long* __restrict__ src, long n,
+                              double* __restrict__ buf) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long q = src[t];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) buf[e * n + t] = a.p[e][q];
+}
+__global__ void k_halo_scatter(Planes5 a, const long* __restrict__ dst, long n,
+                               const double* __restrict__ buf) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long q = dst[t];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) a.p[e][q] = buf[e * n + t];
+}
+
+// ---------------------------------------------------------------------------
+// time advance + residual norms.  Counterpart of procBlock::UpdateBlock
+// procBlock.cpp:826-872 (ExplicitEulerTimeAdvance :882, RK4TimeAdvance :927,
+// ImplicitTimeAdvance :902).  Norm partials: per-block sums of r^2 per
+// equation and the signed max residual with its first (k,j,i,eqn) location;
+// a second kernel folds the partials in a fixed order (reproducible).
+struct NormPartial { double l2[AGX_NEQ]; double vmax; long long lin; };
+
+__device__ __forceinline__ void norm_block_reduce(const double* r, long lin0,
+                                                  bool active,
+                                                  NormPartial* out) {
+  __shared__ double sh[AGX_NEQ + 1][4];
+  __shared__ long long shl[4];
+  double v[AGX_NEQ];
+  double vmax = -1.0e300;
+  long long lin = 0x7fffffffffffffffLL;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    v[e] = active ? r[e] * r[e] : 0.0;
+    if (active && r[e] > vmax) { vmax = r[e]; lin = lin0 + e; }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) v[e] += __shfl_down(v[e], off, 64);
+    const double ov = __shfl_down(vmax, off, 64);
+    const long long ol = __shfl_down(lin, off, 64);
+    if (ov > vmax || (ov == vmax && ol < lin)) { vmax = ov; lin = ol; }
+  }
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) sh[e][wave] = v[e];
+    sh[AGX_NEQ][wave] = vmax;
+    shl[wave] = lin;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+    NormPartial p;
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      double s = 0.0;
+      for (int w = 0; w < nw; ++w) s += sh[e][w];
+      p.l2[e] = s;
+    }
+    p.vmax = sh[AGX_NEQ][0];
+    p.lin = shl[0];
+    for (int w = 1; w < nw; ++w)
+      if (sh[AGX_NEQ][w] > p.vmax || (sh[AGX_NEQ][w] == p.vmax && shl[w] < p.lin)) {
+        p.vmax = sh[AGX_NEQ][w];
+        p.lin = shl[w];
+      }
+    *out = p;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_update(BlockDev b, GasDev g, SolverDev sp, int mode, double alpha, int last_mm,
+         NormPartial* partials) {
+  // mode: 0 explicit Euler, 1 RK stage, 2 implicit
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  const bool active = i < b.ni && j < b.nj;
+  double r[AGX_NEQ] = {0, 0, 0, 0, 0};
+  if (active) {
+    const long q = b.idx(i, j, k);
+    load5(b.resid, q, r);
+    double s[AGX_NEQ], u[AGX_NEQ], ns[AGX_NEQ];
+    load5(b.state, q, s);
+    if (mode == 0) {
+      prim_to_cons(g, s, u);
+      const double fac = b.dt[q] / b.vol[q];
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) u[e] -= fac * r[e];
+      cons_to_prim(g, u, ns);
+    } else if (mode == 1) {
+      const double fac = b.dt[q] / b.vol[q] * alpha;
+      load5(b.consn, q, u);
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) u[e] -= fac * r[e];
+      cons_to_prim(g, u, ns);
+    } else {
+      double du[AGX_NEQ];
+      load5(b.x, q, du);
+      update_prim_with_cons(g, s, du, ns);
+      b.a[q] = 0.0;                       // gridLevel::ResetDiagonal
+      if (sp.bdf2 && last_mm) {           // gridLevel.cpp:425-428
+        load5(b.consn, q, u);
+        store5(b.consnm1, q, u);
+      }
+    }
+    store5(b.state, q, ns);
+  }
+  const long lin0 = (((long)k * b.nj + j) * b.ni + i) * AGX_NEQ;
+  const long bid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  norm_block_reduce(r, lin0, active, partials + bid);
+}
+
+__global__ void k_norm_final(const NormPartial* partials, long n, NormPartial* out) {
+  __shared__ NormPartial sh[256];
+  NormPartial p;
+  for (int e = 0; e < AGX_NEQ; ++e) p.l2[e] = 0.0;
+  p.vmax = -1.0e300;
+  p.lin = 0x7fffffffffffffffLL;
+  for (long t = threadIdx.x; t < n; t += blockDim.x) {
+    const NormPartial o = partials[t];
+    for (int e = 0; e < AGX_NEQ; ++e) p.l2[e] += o.l2[e];
+    if (o.vmax > p.vmax || (o.vmax == p.vmax && o.lin < p.lin)) { p.vmax = o.vmax; p.lin = o.lin; }
+  }
+  sh[threadIdx.x] = p;
+  __syncthreads();
+  for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      NormPartial a = sh[threadIdx.x], o = sh[threadIdx.x + off];
+      for (int e = 0; e < AGX_NEQ; ++e) a.l2[e] += o.l2[e];
+      if (o.vmax > a.vmax || (o.vmax == a.vmax && o.lin < a.lin)) { a.vmax = o.vmax; a.lin = o.lin; }
+      sh[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+
+// procBlock::AssignSolToTimeN / AssignSolToTimeNm1 procBlock.cpp:1037-1054
+__global__ void __launch_bounds__(256)
+k_store_time_n(BlockDev b, GasDev g, int also_nm1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  double s[AGX_NEQ], u[AGX_NEQ];
+  load5(b.state, q, s);
+  prim_to_cons(g, s, u);
+  store5(b.consn, q, u);
+  if (also_nm1) store5(b.consnm1, q, u);
+}
+
+// ---------------------------------------------------------------------------
+// implicit: scalar LU-SGS / DPLUR.
+// b-term of linearSolver.cpp:370-374 with procBlock::SolDeltaMmN / SolDeltaNm1
+// procBlock.cpp:1010-1035
+__device__ __forceinline__ void rhs_b(const BlockDev& b, const GasDev& g,
+                                      const SolverDev& sp, long q, double* out) {
+  double s[AGX_NEQ], u[AGX_NEQ], un[AGX_NEQ], r[AGX_NEQ];
+  load5(b.state, q, s);
+  load5(b.consn, q, un);
+  load5(b.resid, q, r);
+  prim_to_cons(g, s, u);
+  const double vdt = b.vol[q] / (b.dt[q] * sp.theta);
+  const double cN = vdt * (1.0 + sp.zeta);
+  const double thetaInv = 1.0 / sp.theta;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) out[e] = -thetaInv * r[e] - cN * (u[e] - un[e]);
+  if (sp.bdf2) {
+    double um[AGX_NEQ];
+    load5(b.consnm1, q, um);
+    const double cM = vdt * sp.zeta;
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) out[e] += cM * (un[e] - um[e]);
+  }
+}
+
+// procBlock::ImplicitLower / ImplicitUpper procBlock.cpp:1056-1163 with
+// ProjC2CDist :6316-6342; accumulates (L - U) or parts of it.
+__device__ __forceinline__ void add_off_diag(const BlockDev& b, const GasDev& g,
+                                             const SolverDev& sp,
+                                             double* const* x, int i, int j,
+                                             int k, long q, bool lower,
+                                             double sign, double* acc) {
+  const int c[3] = {i, j, k};
+  const int nn[3] = {b.ni, b.nj, b.nk};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const long s = b.stride(d);
+    bool use;
+    long qn, qf;
+    if (lower) {
+      use = c[d] > 0 || bc_is_connection(b, i, j, k, 2 * d + 1);
+      qn = q - s; qf = q;
+    } else {
+      const int o[3] = {d == 0, d == 1, d == 2};
+      use = c[d] < nn[d] - 1 ||
+            bc_is_connection(b, i + o[0], j + o[1], k + o[2], 2 * d + 2);
+      qn = q + s; qf = q + s;
+    }
+    if (!use) continue;
+    double area[4], sn[AGX_NEQ], du[AGX_NEQ], od[AGX_NEQ];
+    load_area(b, d, qf, area);
+    load5(b.state, qn, sn);
+    load5(x, qn, du);
+    double dist = 1.0, mu = 0.0;
+    if (sp.viscous) {
+      const long ql = qf - s;   // cells across face qf: ql | qf
+      const double v[3] = {b.cen[0][qf] - b.cen[0][ql], b.cen[1][qf] - b.cen[1][ql],
+                           b.cen[2][qf] - b.cen[2][ql]};
+      dist = dot3(v, area);
+      mu = viscosity(g, temperature(g, sn));
+    }
+    off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) acc[e] += sign * od[e];
+  }
+}
+
+// linearSolver::AddDiagonalTerms :146-175, Invert :177-188,
+// InitializeMatrixUpdate :111-144
+__global__ void __launch_bounds__(256)
+k_implicit_begin(BlockDev b, GasDev g, SolverDev sp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  double dvt = (b.vol[q] * (1.0 + sp.zeta)) / (b.dt[q] * sp.theta);
+  if (sp.dual_time_cfl > 0.0) dvt += fmax(b.specrad[q], 0.0) / sp.dual_time_cfl;
+  const double a = b.a[q] * sp.relax + dvt;
+  const double ainv = 1.0 / a;
+  b.a[q] = a;
+  b.ainv[q] = ainv;
+  double x0[AGX_NEQ] = {0, 0, 0, 0, 0};
+  if (sp.requires_init) {
+    rhs_b(b, g, sp, q, x0);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) x0[e] *= ainv;
+  }
+  store5(b.x, q, x0);
+}
+__global__ void k_zero5(Planes5 a, long n) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) a.p[e][t] = 0.0;
+}
+__global__ void k_copy5(Planes5 dst, Planes5 src, long n) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) dst.p[e][t] = src.p[e][t];
+}
+
+// One hyperplane i+j+k = p of lusgs::LUSGS_Forward linearSolver.cpp:341-383 /
+// LUSGS_Backward :385-428.  Cells of a plane are mutually independent
+// (HyperplaneReorder utility.cpp:377-398); planes are launched in order.
+template <bool FORWARD>
+__global__ void k_lusgs_plane(BlockDev b, GasDev g, SolverDev sp, int plane, int full) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y * blockDim.y + threadIdx.y;
+  if (j >= b.nj || k >= b.nk) return;
+  const int i = plane - j - k;
+  if (i < 0 || i >= b.ni) return;
+  const long q = b.idx(i, j, k);
+  const double ainv = b.ainv[q];
+  double acc[AGX_NEQ] = {0, 0, 0, 0, 0};
+  if (FORWARD) {
+    add_off_diag(b, g, sp, b.x, i, j, k, q, true, 1.0, acc);
+    if (full) add_off_diag(b, g, sp, b.x, i, j, k, q, false, -1.0, acc);
+    double rb[AGX_NEQ];
+    rhs_b(b, g, sp, q, rb);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) acc[e] = (rb[e] + acc[e]) * ainv;
+  } else {
+    add_off_diag(b, g, sp, b.x, i, j, k, q, false, -1.0, acc);
+    if (full) {
+      add_off_diag(b, g, sp, b.x, i, j, k, q, true, 1.0, acc);
+      double rb[AGX_NEQ];
+      rhs_b(b, g, sp, q, rb);
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) acc[e] = (rb[e] + acc[e]) * ainv;
+    } else {
+      double xo[AGX_NEQ];
+      load5(b.x, q, xo);
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) acc[e] = xo[e] + acc[e] * ainv;
+    }
+  }
+  store5(b.x, q, acc);
+}
+
+// dplur::DPLUR linearSolver.cpp:473-507 (point Jacobi on the copied xold)
+__global__ void __launch_bounds__(256)
+k_dplur(BlockDev b, GasDev g, SolverDev sp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  double acc[AGX_NEQ] = {0, 0, 0, 0, 0}, rb[AGX_NEQ];
+  add_off_diag(b, g, sp, b.xold, i, j, k, q, true, 1.0, acc);
+  add_off_diag(b, g, sp, b.xold, i, j, k, q, false, -1.0, acc);
+  rhs_b(b, g, sp, q, rb);
+  const double ainv = b.ainv[q];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) acc[e] = (rb[e] + acc[e]) * ainv;
+  store5(b.x, q, acc);
+}
+
+// linearSolver::AXmB :58-90 / Residual :92-109 as a pure reduction
+__global__ void __launch_bounds__(256)
+k_matrix_resid(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  const bool active = i < b.ni && j < b.nj;
+  double r[AGX_NEQ] = {0, 0, 0, 0, 0};
+  if (active) {
+    const long q = b.idx(i, j, k);
+    double acc[AGX_NEQ] = {0, 0, 0, 0, 0}, rb[AGX_NEQ], xc[AGX_NEQ];
+    add_off_diag(b, g, sp, b.x, i, j, k, q, true, 1.0, acc);
+    add_off_diag(b, g, sp, b.x, i, j, k, q, false, -1.0, acc);
+    rhs_b(b, g, sp, q, rb);
+    load5(b.x, q, xc);
+    const double a = b.a[q];
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) r[e] = -(xc[e] * a - acc[e] - rb[e]);
+  }
+  const long bid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  norm_block_reduce(r, 0, active, partials + bid);
+}
+
+// ---------------------------------------------------------------------------
+// AoS (reference host layout) <-> SoA conversion at the boundary
+__global__ void k_aos_to_soa(const double* __restrict__ aos, Planes5 soa, int ncomp,
+                             int ci, int cj, int ck, int gsrc, BlockDev b) {
+  // aos dims (ci, cj, ck) with gsrc ghost layers, i fastest, ncomp per cell
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)ci * cj * ck;
+  if (t >= n) return;
+  const int i = (int)(t % ci) - gsrc, j = (int)((t / ci) % cj) - gsrc,
+            k = (int)(t / ((long)ci * cj)) - gsrc;
+  const long q = b.idx(i, j, k);
+  for (int e = 0; e < ncomp; ++e) soa.p[e][q] = aos[t * ncomp + e];
+}
+__global__ void k_soa_to_aos(double* __restrict__ aos, Planes5 soa, int ncomp,
+                             int ci, int cj, int ck, int gsrc, BlockDev b) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)ci * cj * ck;
+  if (t >= n) return;
+  const int i = (int)(t % ci) - gsrc, j = (int)((t / ci) % cj) - gsrc,
+            k = (int)(t / ((long)ci * cj)) - gsrc;
+  const long q = b.idx(i, j, k);
+  for (int e = 0; e < ncomp; ++e) aos[t * ncomp + e] = soa.p[e][q];
+}
+
+}  // namespace agx

@@ -162,3 +162,75 @@ class Solver:
         for nn in range(iterations):
             out = self.step(nn)
         return out
+
+
+class PhasedSolver(Solver):
+    """One rank of a multi-process run: blocks whose `rank` matches are local,
+    connections to other ranks exchange halo slabs between the phases of
+    agx_iterate (include/aither_gfx950.h "phases").
+
+    `exchange(items)` is supplied by the caller: items is a list of
+    (peer_rank, tag, send_tensor, recv_tensor); it must complete all transfers
+    (torch.distributed batch_isend_irecv over RCCL on GPUs, gloo on CPU).
+    `alloc(n)` returns a float64 tensor of n elements on the backend's memory
+    (torch.cuda for the product library, CPU for the test oracle).
+    This is the drop-in replacement of the reference's MPI path
+    (multiArray3d.hpp:830-866 SwapSliceParallel, utility.cpp:400-423).
+    """
+
+    def __init__(self, api, case, rank, exchange, alloc, device=0, stream=None):
+        super().__init__(api, case, device=device, rank=rank, stream=stream)
+        self.exchange, self.alloc = exchange, alloc
+        self.remote = []
+        for n, conn in enumerate(case.connections):
+            if rank in conn.rank and conn.rank[0] != conn.rank[1]:
+                side = 0 if conn.rank[0] == rank else 1
+                cnt = self.api.halo_count(self.ctx, self.conn_ids[n], 0)
+                self.remote.append(dict(
+                    cid=self.conn_ids[n], tag=n, peer=conn.rank[1 - side],
+                    send=self.alloc(cnt), recv=self.alloc(cnt)))
+
+    def _halo(self, what):
+        api = self.api
+        api.check(api.halo_swap_local(self.ctx, what), "halo_swap_local")
+        if not self.remote:
+            return
+        for r in self.remote:
+            api.check(api.halo_pack(self.ctx, r["cid"], what,
+                                    C.c_void_p(r["send"].data_ptr())), "halo_pack")
+        api.check(api.sync(self.ctx), "sync")
+        self.exchange([(r["peer"], r["tag"], r["send"], r["recv"])
+                       for r in self.remote])
+        for r in self.remote:
+            api.check(api.halo_unpack(self.ctx, r["cid"], what,
+                                      C.c_void_p(r["recv"].data_ptr())),
+                      "halo_unpack")
+
+    def iterate(self, mm, cfl):
+        api, ctx, cfg = self.api, self.ctx, self.cfg
+        l2 = np.zeros(cfg.n_eq)
+        linf = abi.Linf()
+        mres = C.c_double(0.0)
+        l2p = l2.ctypes.data_as(abi.c_dp)
+        api.check(api.phase_bc_faces(ctx), "phase_bc_faces")
+        self._halo(abi.HALO_STATE)
+        api.check(api.phase_bc_edges(ctx), "phase_bc_edges")
+        api.check(api.phase_residual(ctx, cfl), "phase_residual")
+        if self.case.deck.is_implicit():
+            api.check(api.phase_implicit_begin(ctx), "phase_implicit_begin")
+            lusgs = cfg.matrix_solver == abi.SOLVER["lusgs"]
+            for s in range(cfg.matrix_sweeps):
+                self._halo(abi.HALO_UPDATE)
+                api.check(api.phase_relax_forward(ctx, s), "relax_forward")
+                if lusgs:
+                    self._halo(abi.HALO_UPDATE)
+                    api.check(api.phase_relax_backward(ctx, s), "relax_backward")
+            self._halo(abi.HALO_UPDATE)
+            api.check(api.phase_matrix_residual(ctx, C.byref(mres)),
+                      "matrix_residual")
+            api.check(api.phase_implicit_update(ctx, mm, l2p, C.byref(linf)),
+                      "implicit_update")
+        else:
+            api.check(api.phase_explicit_update(ctx, mm, l2p, C.byref(linf)),
+                      "explicit_update")
+        return l2, linf, mres.value

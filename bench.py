@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the accelerated hot path.
+
+Metric (BASELINE.json): Mcell-updates/s per iteration, where one iteration is
+one mgSolution::Iterate call (src/mgSolution.cpp:246) = one RK stage of the
+explicit-RK4 residual sweep, on a synthetic single-species 256^3-cell block
+(MUSCL thirdOrder + vanAlbada + Roe, slip walls, smooth perturbation) with the
+state resident in HBM.  `--workload lusgs` times BASELINE configs[2] instead
+(WENO5 + AUSMPW+ + viscous + LU-SGS).
+
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling, one
+256^3 block per rank stacked along k and joined by interblock connections;
+ghost slabs are exchanged with RCCL point-to-point between the phases of the
+iteration (aither_amd.solver.PhasedSolver).
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import aither_amd
+from aither_amd import abi
+from aither_amd.case import synthetic
+from aither_amd.case import builder as _b
+from aither_amd.case import geometry as _geo
+from aither_amd.case import connections as _conn
+from aither_amd.solver import Solver, PhasedSolver
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+BYTES_STAGE = 296          # explicit stage, nEq = 5
+BYTES_RESID_KERNEL = 216   # of which the residual kernel: state 5 + areas 12 +
+                           # widths 3 + vol 1 read, residual 5 + dt 1 written
+BYTES_LUSGS_ITER = 1296    # scalar LU-SGS viscous iteration
+
+
+def deck_kwargs(workload):
+    if workload == "rk4":
+        return dict(time_integration="rk4", cfl=0.5,
+                    face_reconstruction="thirdOrder", limiter="vanAlbada",
+                    inviscid_flux="roe")
+    return dict(equation_set="navierStokes", face_reconstruction="weno",
+                limiter="none", inviscid_flux="ausm",
+                time_integration="implicitEuler", matrix_solver="lusgs",
+                matrix_sweeps=1, cfl=10.0)
+
+
+def rank_local_chain_case(rank, nranks, n, workload):
+    """Block `rank` of a chain of nranks identical n^3 blocks stacked along k.
+    Only this rank's block is built at full size; its neighbours are built
+    four cells thick, which is all the ghost-geometry exchange reads."""
+    kw = deck_kwargs(workload)
+    bcs = None
+    if workload == "lusgs":
+        bcs = {3: ("viscousWall", 2), 1: ("characteristic", 1),
+               2: ("characteristic", 1), 4: ("characteristic", 1)}
+    if nranks == 1:
+        return synthetic.single_block_case((n, n, n), stretch=1.2, bcs=bcs,
+                                           amplitude=0.05, **kw)
+    deck = synthetic.make_deck(**kw)
+    thin = 4
+    coords, all_bcs, dims = [], [], []
+    for b in range(nranks):
+        nk = n if b == rank else thin
+        # the block occupies z in [b, b+1]; thin neighbours keep the spacing
+        # 1/n next to the shared face
+        if b == rank:
+            z0, lz = float(b), 1.0
+        elif b < rank:
+            z0, lz = float(b + 1) - thin / n, thin / n
+        else:
+            z0, lz = float(b), thin / n
+        x = synthetic.box_nodes(n, n, nk, 1.0, lengths=(1.0, 1.0, lz),
+                                origin=(0.0, 0.0, z0))
+        ax = (np.arange(n + 1) / n) ** 1.2
+        x[..., 0] = ax.reshape(1, 1, n + 1)
+        x[..., 1] = ax.reshape(1, n + 1, 1)
+        coords.append(x)
+        blk = dict(bcs or {})
+        if b > 0:
+            blk[5] = ("interblock", 6000 + (b - 1))
+        if b < nranks - 1:
+            blk[6] = ("interblock", 5000 + (b + 1))
+        all_bcs.append(synthetic.box_surfaces(n, n, nk, blk))
+        dims.append(nk)
+    deck.bcs = all_bcs
+    # only neighbours matter: drop the rest to save host memory
+    keep = [b for b in range(nranks) if abs(b - rank) <= 1]
+    sub_deck_bcs = [all_bcs[b] for b in keep]
+    remap = {b: i for i, b in enumerate(keep)}
+    for surfs in sub_deck_bcs:
+        for s in surfs:
+            if s.bc_type == "interblock":
+                pb = s.partner_block()
+                if pb in remap:
+                    s.tag = 1000 * s.partner_surface() + remap[pb]
+                else:      # connection to a block this rank does not hold
+                    s.bc_type, s.tag = "slipWall", 0
+    deck.bcs = sub_deck_bcs
+    case = _b.build_case(None, deck=deck, coords=[coords[b] for b in keep],
+                         ranks=keep)
+    # rank ids are the global block ids (one block per rank)
+    for c in case.connections:
+        c.rank = [keep[c.block[0]], keep[c.block[1]]]
+    for i, blk in enumerate(case.blocks):
+        blk.rank = keep[i]
+        blk.parent = blk.global_pos = keep[i]
+    synthetic.perturbed_state(case, 0.05)
+    case.total_cells = n * n * n * nranks
+    return case
+
+
+def cpu_baseline(workload, budget_s=12.0):
+    """The CPU oracle (a from-scratch scalar port of the reference algorithm,
+    NOT the reference binary) on a bounded sample of the same workload."""
+    lib = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")],
+                              stdout=subprocess.DEVNULL)
+    ora = abi.Api(ctypes.CDLL(lib), "ora_")
+    n = 48
+    case = rank_local_chain_case(0, 1, n, workload)
+    s = Solver(ora, case)
+    s.store_time_n(0)
+    s.iterate(0, 0.5)                      # warm-up
+    its, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        if its % 4 == 0:
+            s.store_time_n(its // 4)
+        s.iterate(its % 4, case.deck.cfl(0))
+        its += 1
+    dt = time.perf_counter() - t0
+    s.close()
+    return dict(value=n ** 3 * its / dt / 1e6, unit="Mcell-updates/s", cores=1,
+                kind="port",
+                sample=f"{its} iterations of the same scheme on a {n}^3 block "
+                       f"({dt:.1f} s, oracle/liboracle.so, gcc -O2, 1 thread)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--workload", choices=["rk4", "lusgs"], default="rk4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    api = aither_amd.load()
+    n = args.size
+    case = rank_local_chain_case(rank, world, n, args.workload)
+    nonlin = case.deck.nonlinear_iterations
+    if world > 1:
+        def exchange(items):
+            ops = []
+            for peer, tag, send, recv in items:
+                ops.append(dist.P2POp(dist.isend, send, peer, tag=tag))
+                ops.append(dist.P2POp(dist.irecv, recv, peer, tag=tag))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            torch.cuda.current_stream().synchronize()
+
+        def alloc(cnt):
+            return torch.empty(max(int(cnt), 1), dtype=torch.float64, device="cuda")
+        sol = PhasedSolver(api, case, rank, exchange, alloc, device=local_rank)
+    else:
+        sol = Solver(api, case, device=local_rank)
+
+    def one_step(it):
+        mm = it % nonlin
+        if mm == 0:
+            sol.store_time_n(it // nonlin)
+        return sol.iterate(mm, case.deck.cfl(it // nonlin))
+
+    it = 0
+    for _ in range(args.warmup):
+        one_step(it)
+        it += 1
+    api.check(api.timing_reset(sol.ctx))
+    api.check(api.timing_enable(sol.ctx, 1))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        l2, linf, mres = one_step(it)
+        it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    api.check(api.timing_enable(sol.ctx, 0))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not np.all(np.isfinite(l2)):
+        raise SystemExit("non-finite residual")
+
+    def group(g):
+        ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
+        api.check(api.timing_get(sol.ctx, g, ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
+    if rank == 0:
+        cells_rank = n ** 3
+        total_cells = cells_rank * world
+        value = total_cells * args.steps / elapsed / 1e6
+        t_res, n_res = group(0)
+        t_upd, n_upd = group(1)
+        t_bc, n_bc = group(2)
+        t_swp, n_swp = group(3)
+        launches_per_step = n_res / max(args.steps, 1)
+        if args.workload == "rk4":
+            # dominant kernel: k_inv_residual (one launch per stage per block)
+            achieved = BYTES_RESID_KERNEL * cells_rank / (t_res * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel="k_inv_residual<MUSCL,vanAlbada,Roe>",
+                        achieved=achieved, peak=HBM_PEAK / 1e9, unit="GB/s",
+                        frac=achieved * 1e9 / HBM_PEAK, traffic=None,
+                        bytes_per_cell=BYTES_RESID_KERNEL,
+                        avg_launch_ms=t_res,
+                        stage=dict(bytes_per_cell=BYTES_STAGE,
+                                   device_ms=t_res * launches_per_step + t_upd,
+                                   frac=BYTES_STAGE * cells_rank /
+                                   ((t_res * launches_per_step + t_upd) * 1e-3) / HBM_PEAK))
+        else:
+            dev_ms = (t_res * n_res + t_upd * n_upd + t_bc * n_bc +
+                      t_swp * n_swp) / max(args.steps, 1)
+            achieved = BYTES_LUSGS_ITER * cells_rank / (dev_ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel="LU-SGS iteration (all kernels)",
+                        achieved=achieved, peak=HBM_PEAK / 1e9, unit="GB/s",
+                        frac=achieved * 1e9 / HBM_PEAK, traffic=None,
+                        bytes_per_cell=BYTES_LUSGS_ITER, avg_launch_ms=dev_ms,
+                        sweep_ms=t_swp * n_swp / max(args.steps, 1))
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            with open(tp) as fh:
+                roof["traffic"] = json.load(fh).get(args.workload)
+        out = {
+            "metric": "Mcell-updates/sec per iteration (residual + update), "
+                      f"{n}^3 block",
+            "value": value, "unit": "Mcell-updates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": (
+                f"single {n}^3 block per GPU, single-species air, MUSCL "
+                "thirdOrder + vanAlbada + Roe, RK4 explicit, slip walls"
+                if args.workload == "rk4" else
+                f"single {n}^3 block per GPU, WENO5 + AUSMPW+ + viscous, "
+                "implicit Euler LU-SGS 1 sweep, viscous wall + characteristic"),
+                "iteration": "one mgSolution::Iterate call (one RK stage)"
+                if args.workload == "rk4" else "one nonlinear iteration",
+                "blocks": world, "cells_per_gpu": cells_rank,
+                "halo": "RCCL p2p between phases" if world > 1 else "none"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out))
+    sol.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,44 @@
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _oracle_lib():
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    src = os.path.join(ROOT, "oracle", "oracle.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")],
+                              stdout=subprocess.DEVNULL)
+    return path
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU oracle (test infrastructure): same entry points, prefix ora_."""
+    from aither_amd import abi
+    return abi.Api(ctypes.CDLL(_oracle_lib()), "ora_")
+
+
+@pytest.fixture(scope="session")
+def agx():
+    """The product library; fails (not skips) when it is missing."""
+    import aither_amd
+    return aither_amd.load()
+
+
+def golden_case(name):
+    from aither_amd.case.builder import build_case
+    return build_case(os.path.join(GOLDEN, "cases", name, name + ".inp"))

@@ -1,0 +1,130 @@
+"""Multi-process halo exchange (the replacement of the reference's MPI path)
+rehearsed on CPU: world_size 2 and 3 over gloo, with the CPU oracle standing
+in for the device library behind the same phase API (PhasedSolver).  The GPU
+run differs only in the backend (agx_ instead of ora_) and the transport
+(RCCL instead of gloo)."""
+import ctypes
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, _oracle_lib
+from aither_amd import abi
+from aither_amd.case import synthetic
+from aither_amd.solver import Solver, PhasedSolver
+
+FARFIELD = {s: ("characteristic", 1) for s in range(1, 7)}
+KW = {
+    "rk4": dict(time_integration="rk4", cfl=0.5),
+    "dplur": dict(bcs=FARFIELD, inviscid_flux="ausm", limiter="none",
+                  time_integration="implicitEuler", matrix_solver="dplur",
+                  matrix_sweeps=4, cfl=20.0),
+    "lusgs": dict(face_reconstruction="weno", limiter="none",
+                  time_integration="implicitEuler", cfl=10.0),
+}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _exchange(items):
+    reqs = []
+    for peer, tag, send, recv in items:
+        reqs.append(dist.isend(send, peer, tag=tag))
+        reqs.append(dist.irecv(recv, peer, tag=tag))
+    for r in reqs:
+        r.wait()
+
+
+def _alloc(cnt):
+    return torch.empty(max(int(cnt), 1), dtype=torch.float64)
+
+
+def _make_case(kind, world, builder):
+    if builder == "stacked":
+        return lambda rank: synthetic.stacked_blocks_case(
+            (6, 5, 4), nblocks=world, axis="k", stretch=1.1,
+            ranks=list(range(world)), **KW[kind])
+    sys.path.insert(0, ROOT)
+    import bench
+    return lambda rank: bench.rank_local_chain_case(rank, world, 8, "rk4")
+
+
+def _worker(rank, world, port, kind, builder, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ora = abi.Api(ctypes.CDLL(_oracle_lib()), "ora_")
+    case = _make_case(kind, world, builder)(rank)
+    sol = PhasedSolver(ora, case, rank, _exchange, _alloc)
+    for nn in range(steps):
+        sol.step(nn)
+    (gb,) = sol.block_ids
+    q.put((rank, sol.download("state", gb), sol.download("residual", gb),
+           np.array([h["l2"] ** 2 for h in sol.history])))
+    dist.barrier()
+    sol.close()
+    dist.destroy_process_group()
+
+
+def _run(world, kind, builder, steps=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker,
+                         args=(r, world, port, kind, builder, steps, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, st, rs, l2 = q.get(timeout=300)
+        res[rank] = (st, rs, l2)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,kind", [(2, "rk4"), (2, "dplur"), (2, "lusgs"),
+                                        (3, "dplur")])
+def test_phased_multiprocess_matches_single_process(oracle, world, kind):
+    res = _run(world, kind, "stacked")
+    case = synthetic.stacked_blocks_case((6, 5, 4), nblocks=world, axis="k",
+                                         stretch=1.1, **KW[kind])
+    ref = Solver(oracle, case)
+    for nn in range(2):
+        ref.step(nn)
+    ng = case.ng
+    core = lambda a: a[ng:-ng, ng:-ng, ng:-ng]
+    l2sum = sum(res[r][2] for r in range(world))
+    l2ref = np.array([h["l2"] ** 2 for h in ref.history])
+    assert np.allclose(l2sum, l2ref, rtol=1e-12)
+    for r in range(world):
+        assert np.array_equal(core(res[r][0]), core(ref.download("state", r)))
+        assert np.array_equal(res[r][1], ref.download("residual", r))
+    ref.close()
+
+
+def test_bench_rank_local_chain_matches_full_build(oracle):
+    """bench.py builds only its own block at full size (neighbours 4 cells
+    thick); the result must equal the fully built 2-block chain."""
+    res = _run(2, "rk4", "chain", steps=1)
+    case = synthetic.stacked_blocks_case((8, 8, 8), nblocks=2, axis="k",
+                                         stretch=1.2, time_integration="rk4",
+                                         cfl=0.5)
+    ref = Solver(oracle, case)
+    ref.step(0)
+    for r in range(2):
+        assert np.allclose(res[r][1], ref.download("residual", r),
+                           rtol=1e-12, atol=1e-18)
+    ref.close()

@@ -1,0 +1,161 @@
+"""CPU tests of the host layer: input parsing, metrics, connections, halo
+maps, and that both shared libraries export every symbol the header declares.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN, golden_case
+from aither_amd import abi
+from aither_amd.case import connections as conn_mod
+from aither_amd.case import geometry as geo
+from aither_amd.case import synthetic
+from aither_amd.case.inputfile import parse_input
+from aither_amd.solver import Solver
+
+
+def test_header_symbols_match_abi_table():
+    text = open(os.path.join(ROOT, "include", "aither_gfx950.h")).read()
+    declared = set(re.findall(r"\bagx_(\w+)\s*\(", text))
+    assert declared == set(abi.SYMBOLS), declared ^ set(abi.SYMBOLS)
+
+
+def test_product_library_exports_every_symbol():
+    """No compute calls here (no GPU): only load + symbol lookup."""
+    import aither_amd
+    assert os.path.exists(aither_amd.LIB_PATH), \
+        "libaither_gfx950.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(aither_amd.LIB_PATH)
+    for name in abi.SYMBOLS:
+        assert hasattr(lib, "agx_" + name), name
+    api = aither_amd.load()
+    assert b"gfx950" in api.version()
+
+
+def test_product_library_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import aither_amd
+    api = aither_amd.load()
+    ctx = ctypes.c_void_p()
+    rc = api.ctx_create(0, 0, ctypes.byref(ctx))
+    assert rc != 0 and b"no HIP device" in api.last_error()
+
+
+def test_oracle_exports_every_symbol(oracle):
+    for name in abi.SYMBOLS:
+        assert hasattr(oracle, name)
+
+
+def test_parse_shocktube_deck():
+    d = parse_input(os.path.join(GOLDEN, "cases", "shockTube", "shockTube.inp"))
+    assert d.time_integration == "bdf2" and (d.theta, d.zeta) == (1.0, 0.5)
+    assert d.face_reconstruction == "weno" and d.num_ghost_layers() == 3
+    assert d.nonlinear_iterations == 5 and d.dual_time_cfl == 1000
+    assert len(d.bcs) == 2 and d.bcs[0][4].bc_type == "slipWall"
+    s = [s for s in d.bcs[0] if s.bc_type == "interblock"][0]
+    assert (s.partner_surface(), s.partner_block()) == (5, 1)
+    assert d.ic_for_block(1).get("density") == 0.153125
+
+
+def test_metrics_closed_cells_and_volume():
+    x = synthetic.box_nodes(6, 5, 4, stretch=1.3, skew=0.02)
+    m = geo.interior_metrics(x)
+    av = lambda f: f[..., :3] * f[..., 3:4]
+    ai, aj, ak = av(m["farea_i"]), av(m["farea_j"]), av(m["farea_k"])
+    closed = (ai[:, :, 1:] - ai[:, :, :-1]) + (aj[:, 1:] - aj[:, :-1]) + \
+        (ak[1:] - ak[:-1])
+    assert np.abs(closed).max() < 1e-14
+    # divergence theorem: sum of x.n A over the boundary = 3 V
+    assert m["vol"].sum() > 0
+    fc = m["fcen_i"]
+    tot = (fc[:, :, -1] * ai[:, :, -1]).sum() - (fc[:, :, 0] * ai[:, :, 0]).sum()
+    fc = m["fcen_j"]
+    tot += (fc[:, -1] * aj[:, -1]).sum() - (fc[:, 0] * aj[:, 0]).sum()
+    fc = m["fcen_k"]
+    tot += (fc[-1] * ak[-1]).sum() - (fc[0] * ak[0]).sum()
+    assert abs(tot / 3.0 - m["vol"].sum()) < 2e-3 * m["vol"].sum()
+
+
+def test_uniform_box_ghost_geometry():
+    case = synthetic.single_block_case((5, 4, 3), amplitude=0.0)
+    g = case.blocks[0].geom
+    ng = g.ng
+    # widths are uniform everywhere except corners
+    for d, n in zip("ijk", (5, 4, 3)):
+        w = g.width[d].a[ng:-ng, ng:-ng, :, 0] if d == "i" else \
+            g.width[d].a[ng:-ng, :, ng:-ng, 0] if d == "j" else \
+            g.width[d].a[:, ng:-ng, ng:-ng, 0]
+        assert np.allclose(w, 1.0 / n, rtol=1e-13)
+    assert np.allclose(g.vol.a[ng:-ng, ng:-ng, :, 0], 1.0 / 60.0, rtol=1e-13)
+
+
+def test_connection_detection_shocktube():
+    case = golden_case("shockTube")
+    assert len(case.connections) == 1
+    c = case.connections[0]
+    assert c.orientation == 1 and c.is_interblock
+    assert sorted(c.boundary) == [5, 6]
+
+
+def test_periodic_connection_couette():
+    case = golden_case("couette")
+    (c,) = case.connections
+    assert not c.is_interblock and c.block == [0, 0] and c.orientation == 1
+
+
+def test_halo_maps_python_vs_oracle(oracle):
+    """insert_maps (numpy restatement of GetSwapLoc) and the oracle's C
+    restatement move the same cells."""
+    case = synthetic.stacked_blocks_case((4, 3, 5), nblocks=2, axis="j",
+                                         amplitude=0.05)
+    sol = Solver(oracle, case)
+    ng = case.ng
+    for gb, blk in enumerate(case.blocks):
+        st = np.arange(blk.state.size, dtype=float).reshape(blk.state.shape) + \
+            1e6 * gb
+        sol.upload("state", gb, st)
+        blk._probe = st
+    oracle.check(oracle.halo_swap_local(sol.ctx, abi.HALO_STATE))
+    (c,) = case.connections
+    b0, b1 = case.blocks
+    d0, s1, _ = conn_mod.insert_maps(c, True, ng, b0.geom.n, b1.geom.n)
+    d1, s0, _ = conn_mod.insert_maps(c, False, ng, b1.geom.n, b0.geom.n)
+    e0 = b0._probe.reshape(-1, 5).copy()
+    e1 = b1._probe.reshape(-1, 5).copy()
+    e0[d0] = b1._probe.reshape(-1, 5)[s1]
+    e1[d1] = b0._probe.reshape(-1, 5)[s0]
+    assert np.array_equal(sol.download("state", 0).reshape(-1, 5), e0)
+    assert np.array_equal(sol.download("state", 1).reshape(-1, 5), e1)
+    sol.close()
+
+
+def test_interblock_matches_single_block(oracle):
+    """Explicit scheme: two stacked blocks give the same residual as the one
+    merged block (ghost cells at the connection equal the neighbour's cells)."""
+    kw = dict(time_integration="rk4", cfl=0.5)
+    two = synthetic.stacked_blocks_case((6, 5, 4), nblocks=2, axis="k",
+                                        amplitude=0.0, **kw)
+    deck = synthetic.make_deck(**kw)
+    deck.bcs = [synthetic.box_surfaces(6, 5, 8)]
+    from aither_amd.case.builder import build_case
+    one = build_case(None, deck=deck,
+                     coords=[synthetic.box_nodes(6, 5, 8, lengths=(1, 1, 2))])
+    synthetic.perturbed_state(two, 0.05)
+    synthetic.perturbed_state(one, 0.05)
+    s2, s1 = Solver(oracle, two), Solver(oracle, one)
+    for s in (s1, s2):
+        s.step(0)
+    r1 = s1.download("residual", 0)
+    r2 = np.concatenate([s2.download("residual", 0),
+                         s2.download("residual", 1)], axis=0)
+    assert np.allclose(r1, r2, rtol=1e-12, atol=1e-16)
+    st1 = s1.download("state", 0)[2:-2, 2:-2, 2:-2]
+    st2 = np.concatenate([s2.download("state", 0)[2:-2, 2:-2, 2:-2],
+                          s2.download("state", 1)[2:-2, 2:-2, 2:-2]], axis=0)
+    assert np.allclose(st1, st2, rtol=1e-12)
+    s1.close(); s2.close()

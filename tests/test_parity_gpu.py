@@ -1,0 +1,155 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle.
+
+Run on a real MI355X:  python -m pytest tests -m gpu
+Tolerance: 1e-10 relative (fp64), stated in parity_utils.RTOL.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_case
+from parity_utils import run_pair, rel_err, RTOL
+from aither_amd.case import synthetic
+from aither_amd.solver import Solver
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(*solvers):
+    for s in solvers:
+        s.close()
+
+
+# ---- the reference's own regression inputs ---------------------------------
+@pytest.mark.parametrize("name,steps", [
+    ("supersonicWedge", 20),      # explicit Euler, MUSCL+vanAlbada+Roe
+    ("subsonicCylinder", 10),     # LU-SGS, stagnationInlet, pressureOutlet
+    ("multiblockCylinder", 10),   # AUSMPW+, characteristic, interblock, CFL ramp
+    ("shockTube", 4),             # WENO5, bdf2 + dual time, 5 nonlinear its
+    ("viscousFlatPlate", 10),     # Navier-Stokes, viscousWall, LU-SGS
+    ("couette", 10),              # periodic, moving isothermal walls
+])
+def test_golden_case_parity(agx, oracle, name, steps):
+    case = golden_case(name)
+    _close(*run_pair(agx, oracle, case, steps))
+
+
+# ---- synthetic 3-D cases: every scheme combination on the hot path ----------
+SLIP = None
+FARFIELD = {s: ("characteristic", 1) for s in range(1, 7)}
+WALL_J = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("pressureOutlet", 3),
+          4: ("characteristic", 1)}
+WALL_ISO = {3: ("viscousWall", 4), 4: ("viscousWall", 2),
+            1: ("characteristic", 1), 2: ("characteristic", 1)}
+
+CASES = {
+    "cfg2_muscl_roe_rk4": dict(n=(14, 12, 10), stretch=1.2, skew=0.01, bcs=SLIP,
+                               time_integration="rk4", cfl=0.5),
+    "minmod_ausm_euler": dict(n=(12, 10, 9), stretch=1.15, bcs=FARFIELD,
+                              limiter="minmod", inviscid_flux="ausm",
+                              time_integration="explicitEuler", cfl=0.4),
+    "constant_roe": dict(n=(10, 9, 8), face_reconstruction="constant",
+                         limiter="none", time_integration="explicitEuler",
+                         cfl=0.4, bcs=FARFIELD),
+    "upwind_none_rk4": dict(n=(10, 9, 8), stretch=1.1, face_reconstruction="upwind",
+                            limiter="none", time_integration="rk4", cfl=0.5),
+    "cfg3_weno_ausm_visc_lusgs": dict(
+        n=(12, 11, 10), stretch=1.2, bcs=WALL_J, equation_set="navierStokes",
+        face_reconstruction="weno", limiter="none", inviscid_flux="ausm",
+        time_integration="implicitEuler", matrix_solver="lusgs", cfl=10.0),
+    "wenoz_roe_bdf2_dual": dict(
+        n=(10, 9, 8), stretch=1.1, face_reconstruction="wenoZ", limiter="none",
+        time_integration="bdf2", nonlinear_iterations=3, dt=2.0e-5,
+        dual_time_cfl=100.0, matrix_sweeps=2),
+    "visc_iso_crank_lusgs": dict(
+        n=(10, 9, 8), stretch=1.15, bcs=WALL_ISO, equation_set="navierStokes",
+        time_integration="crankNicholson", nonlinear_iterations=2, cfl=20.0,
+        limiter="none"),
+    "dplur_muscl_ausm": dict(
+        n=(11, 10, 9), stretch=1.1, bcs=FARFIELD, inviscid_flux="ausm",
+        limiter="none", time_integration="implicitEuler",
+        matrix_solver="dplur", matrix_sweeps=4, cfl=50.0),
+    "visc_explicit_rk4": dict(
+        n=(9, 10, 8), stretch=1.2, bcs=WALL_J, equation_set="navierStokes",
+        time_integration="rk4", cfl=0.3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_synthetic_single_block_parity(agx, oracle, name):
+    case = synthetic.single_block_case(**CASES[name])
+    _close(*run_pair(agx, oracle, case, 3))
+
+
+@pytest.mark.parametrize("axis", ["i", "j", "k"])
+def test_stacked_blocks_parity_dplur(agx, oracle, axis):
+    """BASELINE config 4 in miniature: interblock connections + DPLUR."""
+    case = synthetic.stacked_blocks_case(
+        (8, 7, 6), nblocks=3, axis=axis, stretch=1.1, bcs=FARFIELD,
+        inviscid_flux="ausm", limiter="none", time_integration="implicitEuler",
+        matrix_solver="dplur", matrix_sweeps=4, cfl=20.0)
+    _close(*run_pair(agx, oracle, case, 3))
+
+
+def test_stacked_blocks_parity_lusgs_weno(agx, oracle):
+    case = synthetic.stacked_blocks_case(
+        (8, 7, 6), nblocks=2, axis="k", face_reconstruction="weno",
+        limiter="none", time_integration="implicitEuler", cfl=10.0)
+    _close(*run_pair(agx, oracle, case, 3))
+
+
+# ---- edge cases --------------------------------------------------------------
+@pytest.mark.parametrize("n", [(1, 1, 40), (33, 1, 2), (2, 3, 1), (65, 5, 3)])
+def test_thin_and_ragged_blocks(agx, oracle, n):
+    """Blocks thinner than the ghost depth and sizes that are not multiples of
+    the 64x4 thread tile."""
+    case = synthetic.single_block_case(n=n, stretch=1.0, bcs=None,
+                                       time_integration="rk4", cfl=0.4)
+    _close(*run_pair(agx, oracle, case, 2))
+
+
+def test_download_roundtrip_and_determinism(agx):
+    case = synthetic.single_block_case(n=(20, 9, 7), stretch=1.1)
+    s1, s2 = Solver(agx, case), Solver(agx, case)
+    assert np.array_equal(s1.download("state", 0), case.blocks[0].state)
+    for nn in range(2):
+        s1.step(nn), s2.step(nn)
+    assert np.array_equal(s1.download("state", 0), s2.download("state", 0))
+    assert np.array_equal(s1.history[-1]["l2"], s2.history[-1]["l2"])
+    _close(s1, s2)
+
+
+# ---- BASELINE sizes: oracle at 128^3, size-independent properties at 256^3 ----
+def test_config2_128cubed_one_rk_step(agx, oracle):
+    """configs[1]: single 128^3 block, MUSCL + Roe, RK4 (one full step)."""
+    case = synthetic.single_block_case(n=(128, 128, 128), stretch=1.2,
+                                       time_integration="rk4", cfl=0.5)
+    _close(*run_pair(agx, oracle, case, 1, fields=("state", "residual")))
+
+
+def test_256cubed_freestream_and_conservation(agx):
+    """Full-size properties that need no oracle:
+    (a) a uniform state on a stretched grid with far-field BCs has zero
+        residual (free-stream preservation / metric closure);
+    (b) with slip walls all round, the mass residual sums to zero over the
+        block (every interior face flux appears once with each sign and the
+        wall mass flux vanishes)."""
+    n = (256, 256, 256)
+    far = {s: ("characteristic", 1) for s in range(1, 7)}
+    case = synthetic.single_block_case(n=n, stretch=1.2, bcs=far, amplitude=0.0,
+                                       time_integration="rk4", cfl=0.5)
+    s = Solver(agx, case)
+    s.step(0)
+    r = s.download("residual", 0)
+    st = s.download("state", 0)[2:-2, 2:-2, 2:-2]
+    flux_scale = 1.0 / (256 * 256)            # |A| * rho * u ~ 1e-5
+    assert np.abs(r).max() < 1e-9 * flux_scale
+    assert np.abs(st - case.blocks[0].state[2:-2, 2:-2, 2:-2]).max() < 1e-12
+    s.close()
+    del r, st
+    case = synthetic.single_block_case(n=n, stretch=1.2, bcs=None, amplitude=0.05,
+                                       time_integration="rk4", cfl=0.5)
+    s = Solver(agx, case)
+    s.step(0)
+    r = s.download("residual", 0)[..., 0]
+    assert abs(r.sum()) < 1e-9 * np.abs(r).sum()
+    s.close()
