@@ -33,6 +33,23 @@ def test_golden_case_parity(agx, oracle, name, steps):
     _close(*run_pair(agx, oracle, case, steps))
 
 
+@pytest.mark.parametrize("name,steps", [("subsonicCylinder", 30),
+                                        ("shockTube", 6),
+                                        ("viscousFlatPlate", 20)])
+def test_free_running_drift(agx, oracle, name, steps):
+    """No resync: after `steps` time steps the states still agree to 1e-10."""
+    case = golden_case(name)
+    sg, so = Solver(agx, case), Solver(oracle, case)
+    for nn in range(steps):
+        sg.step(nn), so.step(nn)
+    ng = case.ng
+    for gb in sg.block_ids:
+        a = sg.download("state", gb)[ng:-ng, ng:-ng, ng:-ng]
+        b = so.download("state", gb)[ng:-ng, ng:-ng, ng:-ng]
+        assert rel_err(a, b) < RTOL
+    _close(sg, so)
+
+
 # ---- synthetic 3-D cases: every scheme combination on the hot path ----------
 SLIP = None
 FARFIELD = {s: ("characteristic", 1) for s in range(1, 7)}
