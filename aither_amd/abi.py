@@ -100,7 +100,7 @@ SYMBOLS = {
     "iterate": (_i, [_vp, _i, C.c_double, c_dp, C.POINTER(Linf), c_dp]),
     "phase_bc_faces": (_i, [_vp]),
     "phase_bc_edges": (_i, [_vp]),
-    "phase_residual": (_i, [_vp, C.c_double]),
+    "phase_residual": (_i, [_vp, _i, C.c_double]),
     "phase_explicit_update": (_i, [_vp, _i, c_dp, C.POINTER(Linf)]),
     "phase_implicit_begin": (_i, [_vp]),
     "phase_relax_forward": (_i, [_vp, _i]),

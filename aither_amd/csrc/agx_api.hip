@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 #include <string>
@@ -37,7 +38,8 @@ namespace {
 struct Block {
   BlockDev d;
   int global_pos = 0;
-  std::vector<double*> allocs;
+  double* slab = nullptr;
+  bool state_is_a = true;
   agx_bc_surface* surf_dev = nullptr;
   std::vector<agx_bc_surface> surf_host;
 };
@@ -76,6 +78,10 @@ struct agx_ctx {
   int* err_host = nullptr;              // pinned
   double* halo_buf = nullptr;
   long halo_cap = 0;
+  bool use_gather = false;   // AGX_GATHER=1: one-thread-per-cell gather kernel
+  bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
+  bool fused_pending = false;
+  long fused_parts = 0;
   // timing: hipEvent pairs recorded on the library's stream around each
   // kernel group, resolved lazily in agx_timing_get (no sync while running)
   bool timing = false;
@@ -153,13 +159,6 @@ Planes5 planes(double* const* p, int n = AGX_NEQ) {
   Planes5 r;
   for (int e = 0; e < AGX_NEQ; ++e) r.p[e] = e < n ? p[e] : nullptr;
   return r;
-}
-
-int alloc_plane(agx_ctx* c, Block& b, double** p) {
-  HIPCHK(hipMalloc((void**)p, sizeof(double) * b.d.nplane));
-  HIPCHK(hipMemsetAsync(*p, 0, sizeof(double) * b.d.nplane, c->stream));
-  b.allocs.push_back(*p);
-  return 0;
 }
 
 // upload an AoS host array (dims (ci,cj,ck) incl. gsrc ghosts, ncomp per cell)
@@ -287,31 +286,81 @@ int check_device_error(agx_ctx* c) {
   return 0;
 }
 
+struct MarchPlan { dim3 grid; int kchunk; long nparts; };
+int g_march_tj = 6;   // rows per workgroup: 6 (512 threads) or 14 (1024 threads)
+MarchPlan march_plan(const BlockDev& b) {
+  MarchPlan p;
+  const int gx = (b.ni + 63) / 64, gy = (b.nj + g_march_tj - 1) / g_march_tj;
+  // aim at >= ~2048 workgroups so that all 256 CUs stay busy to the end
+  int nz = std::max(1, (int)std::lround((g_march_tj == 14 ? 1024.0 : 2048.0) / (gx * gy)));
+  nz = std::min(nz, std::max(1, b.nk / 4));
+  p.kchunk = (b.nk + nz - 1) / nz;
+  nz = (b.nk + p.kchunk - 1) / p.kchunk;
+  p.grid = dim3(gx, gy, nz);
+  p.nparts = (long)gx * gy * nz;
+  return p;
+}
+
+template <int RECON, int LIM, int FLUX>
+void launch_inv_kernel(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
+                       const MarchArgs& ma, const MarchPlan& mp) {
+  SlabDev sd;
+  sd.base = b.vol - (long)PL_VOL * b.nplane;
+  sd.nplane = b.nplane; sd.sx = b.sx; sd.sxy = b.sxy;
+  sd.ni = b.ni; sd.nj = b.nj; sd.nk = b.nk; sd.ng = b.ng; sd.ioff = b.ioff;
+  sd.st = (int)((b.state[0] - sd.base) / b.nplane);
+  sd.sn = (int)((b.state2[0] - sd.base) / b.nplane);
+  if (c->use_gather) {
+    hipLaunchKernelGGL((k_inv_residual<RECON, LIM, FLUX>), cell_grid(b, CELL_BLOCK),
+                       CELL_BLOCK, 0, c->stream, b, c->gas, c->sp, cfl);
+    return;
+  }
+  const dim3 tb(64, g_march_tj + 2);
+  if (g_march_tj == 14) {
+    if (fuse)
+      hipLaunchKernelGGL((k_residual_march<RECON, LIM, FLUX, true, 14>), mp.grid, tb, 0,
+                         c->stream, sd, c->gas, c->sp, cfl, ma);
+    else
+      hipLaunchKernelGGL((k_residual_march<RECON, LIM, FLUX, false, 14>), mp.grid, tb, 0,
+                         c->stream, sd, c->gas, c->sp, cfl, ma);
+  } else {
+    if (fuse)
+      hipLaunchKernelGGL((k_residual_march<RECON, LIM, FLUX, true, 6>), mp.grid, tb, 0,
+                         c->stream, sd, c->gas, c->sp, cfl, ma);
+    else
+      hipLaunchKernelGGL((k_residual_march<RECON, LIM, FLUX, false, 6>), mp.grid, tb, 0,
+                         c->stream, sd, c->gas, c->sp, cfl, ma);
+  }
+}
 template <int RECON, int LIM>
-void launch_inv_flux(agx_ctx* c, const BlockDev& b, double cfl) {
-  const dim3 grid = cell_grid(b, CELL_BLOCK);
+void launch_inv_flux(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
+                     const MarchArgs& ma, const MarchPlan& mp) {
   if (c->cfg.inviscid_flux == AGX_FLUX_ROE)
-    hipLaunchKernelGGL((k_inv_residual<RECON, LIM, AGX_FLUX_ROE>), grid,
-                       CELL_BLOCK, 0, c->stream, b, c->gas, c->sp, cfl);
+    launch_inv_kernel<RECON, LIM, AGX_FLUX_ROE>(c, b, cfl, fuse, ma, mp);
   else
-    hipLaunchKernelGGL((k_inv_residual<RECON, LIM, AGX_FLUX_AUSM>), grid,
-                       CELL_BLOCK, 0, c->stream, b, c->gas, c->sp, cfl);
+    launch_inv_kernel<RECON, LIM, AGX_FLUX_AUSM>(c, b, cfl, fuse, ma, mp);
 }
 template <int RECON>
-void launch_inv_lim(agx_ctx* c, const BlockDev& b, double cfl) {
+void launch_inv_lim(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
+                    const MarchArgs& ma, const MarchPlan& mp) {
   switch (c->cfg.limiter) {
-    case AGX_LIMITER_VANALBADA: launch_inv_flux<RECON, AGX_LIMITER_VANALBADA>(c, b, cfl); break;
-    case AGX_LIMITER_MINMOD: launch_inv_flux<RECON, AGX_LIMITER_MINMOD>(c, b, cfl); break;
-    default: launch_inv_flux<RECON, AGX_LIMITER_NONE>(c, b, cfl); break;
+    case AGX_LIMITER_VANALBADA: launch_inv_flux<RECON, AGX_LIMITER_VANALBADA>(c, b, cfl, fuse, ma, mp); break;
+    case AGX_LIMITER_MINMOD: launch_inv_flux<RECON, AGX_LIMITER_MINMOD>(c, b, cfl, fuse, ma, mp); break;
+    default: launch_inv_flux<RECON, AGX_LIMITER_NONE>(c, b, cfl, fuse, ma, mp); break;
   }
 }
-void launch_inv(agx_ctx* c, const BlockDev& b, double cfl) {
+void launch_inv(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
+                const MarchArgs& ma, const MarchPlan& mp) {
   switch (c->cfg.recon) {
-    case AGX_RECON_CONSTANT: launch_inv_flux<AGX_RECON_CONSTANT, AGX_LIMITER_NONE>(c, b, cfl); break;
-    case AGX_RECON_MUSCL: launch_inv_lim<AGX_RECON_MUSCL>(c, b, cfl); break;
-    case AGX_RECON_WENO: launch_inv_flux<AGX_RECON_WENO, AGX_LIMITER_NONE>(c, b, cfl); break;
-    default: launch_inv_flux<AGX_RECON_WENOZ, AGX_LIMITER_NONE>(c, b, cfl); break;
+    case AGX_RECON_CONSTANT: launch_inv_flux<AGX_RECON_CONSTANT, AGX_LIMITER_NONE>(c, b, cfl, fuse, ma, mp); break;
+    case AGX_RECON_MUSCL: launch_inv_lim<AGX_RECON_MUSCL>(c, b, cfl, fuse, ma, mp); break;
+    case AGX_RECON_WENO: launch_inv_flux<AGX_RECON_WENO, AGX_LIMITER_NONE>(c, b, cfl, fuse, ma, mp); break;
+    default: launch_inv_flux<AGX_RECON_WENOZ, AGX_LIMITER_NONE>(c, b, cfl, fuse, ma, mp); break;
   }
+}
+
+bool can_fuse(const agx_ctx* c) {
+  return c->allow_fuse && !c->use_gather && !c->sp.implicit && !c->sp.viscous;
 }
 
 int bc_pass(agx_ctx* c, bool faces, int viscous) {
@@ -349,7 +398,22 @@ int reduce_norms(agx_ctx* c, size_t blk_index, long nparts) {
 
 int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
   const double alpha[4] = {0.25, 1.0 / 3.0, 0.5, 1.0};   // procBlock.cpp:938
-  {
+  if (mode != 2 && c->fused_pending) {
+    // the marching kernel already advanced the state into the second buffer
+    // and left one norm partial per workgroup: fold them and swap buffers
+    Timer t(c, G_UPDATE);
+    long off = 0;
+    for (size_t n = 0; n < c->blocks.size(); ++n) {
+      BlockDev& b = c->blocks[n].d;
+      const MarchPlan mp = march_plan(b);
+      hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, c->stream,
+                         c->partials + off, mp.nparts, c->norm_out + n);
+      off += mp.nparts;
+      for (int e = 0; e < AGX_NEQ; ++e) std::swap(b.state[e], b.state2[e]);
+    }
+    c->fused_pending = false;
+    HIPCHK(hipGetLastError());
+  } else {
     Timer t(c, G_UPDATE);
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       const BlockDev& b = c->blocks[n].d;
@@ -404,6 +468,9 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
   agx_ctx* c = new agx_ctx();
   c->device = device;
   c->rank = rank;
+  c->use_gather = getenv("AGX_GATHER") && atoi(getenv("AGX_GATHER")) != 0;
+  c->allow_fuse = !(getenv("AGX_NO_FUSE") && atoi(getenv("AGX_NO_FUSE")) != 0);
+  if (getenv("AGX_TJ")) g_march_tj = atoi(getenv("AGX_TJ")) == 14 ? 14 : 6;
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
   HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
   HIPCHK(hipHostMalloc((void**)&c->err_host, sizeof(int)));
@@ -417,7 +484,7 @@ void agx_ctx_destroy(agx_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   for (auto& b : c->blocks) {
-    for (double* p : b.allocs) hipFree(p);
+    if (b.slab) hipFree(b.slab);
     if (b.surf_dev) hipFree(b.surf_dev);
   }
   for (auto& k : c->conns) {
@@ -484,18 +551,24 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
   d.sx = (row + 15) / 16 * 16;
   d.sxy = d.sx * (d.nj + 2 * d.ng + 1);
   d.nplane = d.sxy * (d.nk + 2 * d.ng + 1);
-  double** cellp[] = {&d.vol, &d.specrad, &d.dt, &d.a, &d.ainv};
-  for (auto p : cellp) if (alloc_plane(c, b, p)) return 1;
+  // one slab for all planes of the block (see SlabDev in agx_kernels.hpp)
+  HIPCHK(hipMalloc((void**)&b.slab, sizeof(double) * d.nplane * PL_COUNT));
+  HIPCHK(hipMemsetAsync(b.slab, 0, sizeof(double) * d.nplane * PL_COUNT, c->stream));
+  auto pl = [&](int id) { return b.slab + (long)id * d.nplane; };
+  d.vol = pl(PL_VOL); d.specrad = pl(PL_SPECRAD); d.dt = pl(PL_DT);
+  d.a = pl(PL_A); d.ainv = pl(PL_AINV);
   for (int e = 0; e < AGX_NEQ; ++e) {
-    double** ps[] = {&d.state[e], &d.resid[e], &d.consn[e], &d.consnm1[e],
-                     &d.x[e], &d.xold[e]};
-    for (auto p : ps) if (alloc_plane(c, b, p)) return 1;
+    d.state[e] = pl(PL_STATE_A + e); d.state2[e] = pl(PL_STATE_B + e);
+    d.resid[e] = pl(PL_RESID + e); d.consn[e] = pl(PL_CONSN + e);
+    d.consnm1[e] = pl(PL_CONSNM1 + e); d.x[e] = pl(PL_X + e);
+    d.xold[e] = pl(PL_XOLD + e);
   }
   for (int q = 0; q < 3; ++q) {
-    if (alloc_plane(c, b, &d.cen[q])) return 1;
-    if (alloc_plane(c, b, &d.wid[q])) return 1;
-    for (int cc = 0; cc < 4; ++cc) if (alloc_plane(c, b, &d.fa[q][cc])) return 1;
+    d.cen[q] = pl(PL_CEN + q);
+    d.wid[q] = pl(PL_WID + q);
+    for (int cc = 0; cc < 4; ++cc) d.fa[q][cc] = pl(PL_FA + 4 * q + cc);
   }
+  b.state_is_a = true;
   const int ci = d.ni + 2 * d.ng, cj = d.nj + 2 * d.ng, ck = d.nk + 2 * d.ng;
   if (upload_aos(c, b, g->farea_i, d.fa[0], 4, ci + 1, cj, ck, d.ng)) return 1;
   if (upload_aos(c, b, g->farea_j, d.fa[1], 4, ci, cj + 1, ck, d.ng)) return 1;
@@ -542,10 +615,13 @@ int agx_setup_finalize(agx_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
   const int ng = c->cfg.n_ghost;
   long max_parts = 1, max_halo = 1;
+  long march_parts = 0;
   for (auto& blk : c->blocks) {
     const dim3 g = cell_grid(blk.d, CELL_BLOCK);
     max_parts = std::max(max_parts, (long)g.x * g.y * g.z);
+    march_parts += march_plan(blk.d).nparts;
   }
+  max_parts = std::max(max_parts, march_parts);
   for (auto& k : c->conns) {
     const agx_connection& cc = k.c;
     const bool l0 = cc.rank[0] == c->rank, l1 = cc.rank[1] == c->rank;
@@ -645,14 +721,28 @@ int agx_store_time_n(agx_ctx* c, int also_nm1) {
 int agx_phase_bc_faces(agx_ctx* c) { Timer t(c, G_BC); return bc_pass(c, true, 0); }
 int agx_phase_bc_edges(agx_ctx* c) { Timer t(c, G_BC); return bc_pass(c, false, 0); }
 
-int agx_phase_residual(agx_ctx* c, double cfl) {
+int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
   if (c->cfg.dt_nondim <= 0.0 && cfl <= 0.0)
     return fail("Neither dt or cfl was specified!");   // procBlock.cpp:813-816
+  const bool fuse = can_fuse(c);
   {
     Timer t(c, G_RESID);
-    for (auto& blk : c->blocks) launch_inv(c, blk.d, cfl);
+    long off = 0;
+    for (auto& blk : c->blocks) {
+      const MarchPlan mp = march_plan(blk.d);
+      MarchArgs ma;
+      memset(&ma, 0, sizeof ma);
+      ma.kchunk = mp.kchunk;
+      ma.mode = c->cfg.time_integration == AGX_TIME_RK4 ? 1 : 0;
+      const double rk_alpha[4] = {0.25, 1.0 / 3.0, 0.5, 1.0};   // procBlock.cpp:938
+      ma.alpha = rk_alpha[mm & 3];
+      ma.partials = c->partials + off;
+      launch_inv(c, blk.d, cfl, fuse, ma, mp);
+      off += mp.nparts;
+    }
   }
   HIPCHK(hipGetLastError());
+  c->fused_pending = fuse;
   if (c->cfg.is_viscous) {
     {
       Timer t(c, G_BC);
@@ -832,7 +922,7 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
   if (agx_halo_swap_local(c, AGX_HALO_STATE)) return 1;
   if (agx_phase_bc_edges(c)) return 1;
   // gridLevel::CalcResidual :372-400 + CalcTimeStep :240-247
-  if (agx_phase_residual(c, cfl)) return 1;
+  if (agx_phase_residual(c, mm, cfl)) return 1;
   *matrix_resid = 0.0;
   if (c->sp.implicit) {
     // mgSolution::ImplicitUpdate :209-244; lusgs::Relax linearSolver.cpp:430-470;

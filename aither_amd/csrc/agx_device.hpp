@@ -45,17 +45,15 @@ __device__ __forceinline__ double temperature(const GasDev& g, const double* s) 
 __device__ __forceinline__ double sound_speed(const GasDev& g, const double* s) {
   return sqrt(g.gamma * s[4] / s[0]);
 }
-// EnthalpyFunc arrayView.hpp:401-409 (|v| via sqrt then squared, eos.cpp:80-84)
-__device__ __forceinline__ double enthalpy(const GasDev& g, const double* s) {
-  const double t = temperature(g, s);
-  const double vel = sqrt(dot3(s + 1, s + 1));
-  return g.hf + g.R * (g.n + 1.0) * t + 0.5 * vel * vel;
+// rho * H = rho (hf + cp T + |v|^2/2) with rho cp T = (n+1) p: no division,
+// no sqrt (EnthalpyFunc arrayView.hpp:401-409 takes |v| by sqrt and squares
+// it again, eos.cpp:80-84 -- a last-ulp difference, inside the 1e-10 budget)
+__device__ __forceinline__ double rho_enthalpy(const GasDev& g, const double* s) {
+  return s[0] * (g.hf + 0.5 * dot3(s + 1, s + 1)) + (g.n + 1.0) * s[4];
 }
-// InternalEnergy arrayView.hpp:434-443
-__device__ __forceinline__ double total_energy(const GasDev& g, const double* s) {
-  const double t = temperature(g, s);
-  const double vel = sqrt(dot3(s + 1, s + 1));
-  return g.hf + g.R * g.n * t + 0.5 * vel * vel;
+// rho * E (InternalEnergy arrayView.hpp:434-443): rho cv T = n p
+__device__ __forceinline__ double rho_energy(const GasDev& g, const double* s) {
+  return s[0] * (g.hf + 0.5 * dot3(s + 1, s + 1)) + g.n * s[4];
 }
 // PrimToCons primitive.hpp:183-201
 __device__ __forceinline__ void prim_to_cons(const GasDev& g, const double* s,
@@ -64,22 +62,20 @@ __device__ __forceinline__ void prim_to_cons(const GasDev& g, const double* s,
   u[1] = s[0] * s[1];
   u[2] = s[0] * s[2];
   u[3] = s[0] * s[3];
-  u[4] = s[0] * total_energy(g, s);
+  u[4] = rho_energy(g, s);
 }
 // primitive(cons, phys) primitive.hpp:152-178, idealGas::PressFromEnergy
 // eos.cpp:40-52, TemperatureFromSpecEnergy thermodynamic.cpp:108-114
 __device__ __forceinline__ void cons_to_prim(const GasDev& g, const double* u,
                                              double* s) {
   const double rho = u[0];
+  const double ir = 1.0 / rho;
   s[0] = rho;
-  s[1] = u[1] / rho;
-  s[2] = u[2] / rho;
-  s[3] = u[3] / rho;
-  const double en = u[4] / rho;
-  const double vel = sqrt(dot3(s + 1, s + 1));
-  const double spec = en - 0.5 * vel * vel;
-  const double t = (spec - g.hf) / g.cv;
-  s[4] = rho * g.R * t;
+  s[1] = u[1] * ir;
+  s[2] = u[2] * ir;
+  s[3] = u[3] * ir;
+  // p = rho R T, T = (E/rho - |v|^2/2 - hf) / cv  =>  p = (rhoE - rho(...)) / n
+  s[4] = (u[4] - rho * (g.hf + 0.5 * dot3(s + 1, s + 1))) / g.n;
 }
 // UpdatePrimWithCons primitive.hpp:206-231
 __device__ __forceinline__ void update_prim_with_cons(const GasDev& g,
@@ -115,19 +111,34 @@ __device__ __forceinline__ double limiter(double r) {
   return 1.0;
 }
 
-// FaceReconMUSCL reconstruction.hpp:110-154, one variable
+// FaceReconMUSCL reconstruction.hpp:110-154, one variable, ONE division:
+// with num = EPS + (dw1-uw1) dPlus, den = EPS + (uw1-uw2) dMinus, r = num/den,
+//   vanAlbada  L(r) = max(0, r(1+r)/(1+r^2)) = max(0, num s q)
+//              L(1/r)                        = max(0, den s q)
+//   with s = num + den, q = 1/(num^2 + den^2), so r L(1/r) = num s q when
+//   den s > 0 and 0 otherwise;
+//   minmod     r L(1/r) = L(r) = max(0, min(1, r)).
 template <int LIM>
 __device__ __forceinline__ double muscl(double uw2, double uw1, double dw1,
                                         double dPlus, double dMinus,
                                         double kappa) {
   const double dm = (uw1 - uw2) * dMinus;
-  const double r = (AGX_EPS + (dw1 - uw1) * dPlus) / (AGX_EPS + dm);
-  double lim = 1.0, inv = 1.0;
-  if (LIM != AGX_LIMITER_NONE) {
-    lim = limiter<LIM>(r);
-    inv = limiter<LIM>(1.0 / r);
+  const double num = AGX_EPS + (dw1 - uw1) * dPlus;
+  const double den = AGX_EPS + dm;
+  double lim, rinv;
+  if (LIM == AGX_LIMITER_VANALBADA) {
+    const double sq = (num + den) / (num * num + den * den);
+    const double nsq = num * sq;
+    lim = fmax(0.0, nsq);
+    rinv = den * sq > 0.0 ? nsq : 0.0;
+  } else if (LIM == AGX_LIMITER_MINMOD) {
+    lim = fmax(0.0, fmin(1.0, num / den));
+    rinv = lim;
+  } else {
+    lim = 1.0;
+    rinv = num / den;
   }
-  return uw1 + 0.25 * dm * ((1.0 - kappa) * lim + (1.0 + kappa) * r * inv);
+  return uw1 + 0.25 * dm * ((1.0 - kappa) * lim + (1.0 + kappa) * rinv);
 }
 
 // ---- WENO5 on non-uniform widths, reconstruction.hpp:158-310 --------------
@@ -249,11 +260,12 @@ __device__ __forceinline__ void phys_flux(const GasDev& g, const double* s,
   f[1] = m * s[1] + s[4] * n[0];
   f[2] = m * s[2] + s[4] * n[1];
   f[3] = m * s[3] + s[4] * n[2];
-  f[4] = m * enthalpy(g, s);
+  f[4] = vn * rho_enthalpy(g, s);
 }
 
 // RoeFlux inviscidFlux.hpp:260-382 with RoeAveragedState primitive.hpp:245-280
-// (pressure is Roe-averaged, enthalpy derived from it) and Harten's fix 0.1
+// (pressure is Roe-averaged, enthalpy derived from it) and Harten's fix 0.1.
+// 4 divisions + 2 square roots per face.
 __device__ __forceinline__ void roe_flux(const GasDev& g, const double* l,
                                          const double* r, const double* n,
                                          double* flux) {
@@ -263,8 +275,12 @@ __device__ __forceinline__ void roe_flux(const GasDev& g, const double* l,
   roe[0] = l[0] * dr;
 #pragma unroll
   for (int e = 1; e < AGX_NEQ; ++e) roe[e] = (l[e] + dr * r[e]) * inv1;
-  const double hR = enthalpy(g, roe);
-  const double aR = sound_speed(g, roe);
+  const double p_rho = roe[4] / roe[0];
+  const double v2R = dot3(roe + 1, roe + 1);
+  const double hR = g.hf + (g.n + 1.0) * p_rho + 0.5 * v2R;
+  const double a2 = g.gamma * p_rho;
+  const double aR = sqrt(a2);
+  const double inv_a2 = 1.0 / a2;
   const double rhoR = roe[0];
   const double vnR = dot3(roe + 1, n);
   double d[AGX_NEQ];
@@ -272,7 +288,6 @@ __device__ __forceinline__ void roe_flux(const GasDev& g, const double* l,
   for (int e = 0; e < AGX_NEQ; ++e) d[e] = r[e] - l[e];
   const double dvn = dot3(d + 1, n);
   const double fix = 0.1;
-  const double inv_a2 = 1.0 / (aR * aR);
   double diss[AGX_NEQ];
   // left acoustic
   double ws = fabs(vnR - aR);
@@ -285,12 +300,12 @@ __device__ __forceinline__ void roe_flux(const GasDev& g, const double* l,
   diss[4] = wss * (hR - aR * vnR);
   // entropy
   ws = fabs(vnR);
-  diss[0] += ws * (-d[4] * inv_a2) + ws * d[0];
   wss = ws * (d[0] - d[4] * inv_a2);
+  diss[0] += wss;
   diss[1] += wss * roe[1];
   diss[2] += wss * roe[2];
   diss[3] += wss * roe[3];
-  diss[4] += wss * 0.5 * dot3(roe + 1, roe + 1);
+  diss[4] += wss * 0.5 * v2R;
   // shear
   wss = ws * rhoR;
   diss[1] += wss * (d[1] - dvn * n[0]);
@@ -323,7 +338,8 @@ __device__ __forceinline__ void ausm_flux(const GasDev& g, const double* l,
   double c = cS;
   if (vel < 0.0) c = cS * cS / fmax(vnR, cS);
   else if (vel > 0.0) c = cS * cS / fmax(vnL, cS);
-  const double ml = vnL / c, mr = vnR / c;
+  const double ic = 1.0 / c;
+  const double ml = vnL * ic, mr = vnR * ic;
   const double sl = (ml > 0.0) - (ml < 0.0), sr = (mr > 0.0) - (mr < 0.0);
   const bool subl = fabs(ml) <= 1.0, subr = fabs(mr) <= 1.0;
   const double mPlusL = subl ? 0.25 * (ml + 1.0) * (ml + 1.0) : 0.5 * (ml + fabs(ml));
@@ -331,23 +347,22 @@ __device__ __forceinline__ void ausm_flux(const GasDev& g, const double* l,
   const double pPlus = subl ? 0.25 * (ml + 1.0) * (ml + 1.0) * (2.0 - ml) : 0.5 * (1.0 + sl);
   const double pMinus = subr ? 0.25 * (mr - 1.0) * (mr - 1.0) * (2.0 + mr) : 0.5 * (1.0 - sr);
   const double ps = pPlus * l[4] + pMinus * r[4];
-  const double pm = fmin(l[4] / r[4], r[4] / l[4]);
+  const double ips = 1.0 / ps;
+  const double pm = fmin(l[4], r[4]) / fmax(l[4], r[4]);   // min(pL/pR, pR/pL)
   const double w = 1.0 - pm * pm * pm;
-  const double fl = fabs(ml) < 1.0 ? l[4] / ps - 1.0 : 0.0;
-  const double fr = fabs(mr) < 1.0 ? r[4] / ps - 1.0 : 0.0;
+  const double fl = fabs(ml) < 1.0 ? l[4] * ips - 1.0 : 0.0;
+  const double fr = fabs(mr) < 1.0 ? r[4] * ips - 1.0 : 0.0;
   const double mavg = mPlusL + mMinusR;
   const double mPlusLBar = mavg >= 0.0
       ? mPlusL + mMinusR * ((1.0 - w) * (1.0 + fr) - fl) : mPlusL * w * (1.0 + fl);
   const double mMinusRBar = mavg >= 0.0
       ? mMinusR * w * (1.0 + fr) : mMinusR + mPlusL * ((1.0 - w) * (1.0 + fl) - fr);
   const double vl = mPlusLBar * c, vr = mMinusRBar * c;
-  const double ml_ = l[0] * vl, mr_ = r[0] * vr;
-  f[0] = ml_ + mr_;
-  const double pf = pPlus * l[4] + pMinus * r[4];
-  f[1] = ml_ * l[1] + mr_ * r[1] + pf * n[0];
-  f[2] = ml_ * l[2] + mr_ * r[2] + pf * n[1];
-  f[3] = ml_ * l[3] + mr_ * r[3] + pf * n[2];
-  f[4] = ml_ * enthalpy(g, l) + mr_ * enthalpy(g, r);
+  f[0] = l[0] * vl + r[0] * vr;
+  f[1] = l[0] * vl * l[1] + r[0] * vr * r[1] + ps * n[0];
+  f[2] = l[0] * vl * l[2] + r[0] * vr * r[2] + ps * n[1];
+  f[3] = l[0] * vl * l[3] + r[0] * vr * r[3] + ps * n[2];
+  f[4] = vl * rho_enthalpy(g, l) + vr * rho_enthalpy(g, r);
 }
 
 template <int FLUX>

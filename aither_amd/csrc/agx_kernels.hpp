@@ -21,6 +21,7 @@ struct BlockDev {
   long sx, sxy, nplane;       // strides and plane length
   int parent;
   double* state[AGX_NEQ];     // state_                  procBlock.hpp:65
+  double* state2[AGX_NEQ];    // second state buffer (fused explicit update)
   double* fa[3][4];           // fAreaI/J/K_ {nx,ny,nz,|A|}   :71-73
   double* vol;                // vol_                    :81
   double* cen[3];             // center_                 :82
@@ -41,6 +42,34 @@ struct BlockDev {
   }
   __host__ __device__ long stride(int d) const {
     return d == 0 ? 1 : (d == 1 ? sx : sxy);
+  }
+};
+
+struct NormPartial { double l2[AGX_NEQ]; double vmax; long long lin; };
+
+// All planes of a block live in ONE slab, plane p at base + p * nplane, so a
+// kernel needs a single base pointer (2 SGPRs) instead of ~60 plane pointers.
+enum {
+  PL_STATE_A = 0, PL_STATE_B = 5, PL_RESID = 10, PL_CONSN = 15, PL_CONSNM1 = 20,
+  PL_X = 25, PL_XOLD = 30, PL_FA = 35 /* + 4*d + c */, PL_VOL = 47, PL_CEN = 48,
+  PL_WID = 51, PL_SPECRAD = 54, PL_DT = 55, PL_A = 56, PL_AINV = 57, PL_COUNT = 58
+};
+struct SlabDev {               // compact view used by the marching kernel
+  double* base;
+  long nplane, sx, sxy;
+  int ni, nj, nk, ng, ioff;
+  int st, sn;                  // plane ids of the current / next state buffer
+  __device__ __forceinline__ double* pl(int id) const { return base + (long)id * nplane; }
+  __device__ __forceinline__ const double* state(int e) const { return pl(st + e); }
+  __device__ __forceinline__ double* snew(int e) const { return pl(sn + e); }
+  __device__ __forceinline__ const double* wid(int d) const { return pl(PL_WID + d); }
+  __device__ __forceinline__ const double* fa(int d, int c) const { return pl(PL_FA + 4 * d + c); }
+  __device__ __forceinline__ long idx(int i, int j, int k) const {
+    return (long)(k + ng) * sxy + (long)(j + ng) * sx + (i + ioff);
+  }
+  __device__ __forceinline__ void area(int d, long q, double* a) const {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = fa(d, c)[q];
   }
 };
 
@@ -147,6 +176,270 @@ k_inv_residual(BlockDev b, GasDev g, SolverDev sp, double cfl) {
   if (sp.implicit) b.a[q] = sr;
   if (!sp.viscous)
     b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (b.vol[q] / fmax(sr, 0.0));
+}
+
+// ---------------------------------------------------------------------------
+// Inviscid residual, face-once "marching" form (the production kernel).
+//
+// Work decomposition for 64-wide wavefronts, one 1024-thread workgroup
+// (16 waves, 4 per SIMD, <= 128 VGPRs) per tile of 64 (i) x MARCH_TJ (j)
+// cells, marching through a chunk of k planes:
+//   * waves 0..TJ-1   : one wave = one i-row of 64 cells.  Each lane owns one
+//     cell column and computes exactly ONE flux per direction per step: the
+//     lower i-face, the lower j-face and the upper k-face of its cell.
+//   * i hand-off     : the upper i-face flux is the neighbour lane's lower
+//     flux, fetched with a wavefront shuffle (no memory);
+//   * j hand-off     : lower j-face fluxes go through LDS (double buffered,
+//     one barrier per k-step); each row reads the lower flux of the row above
+//     as its own upper flux;
+//   * k hand-off     : marching -- the upper k-face flux of step k stays in
+//     registers and is the lower k-face flux of step k+1 (the k-stencil cells
+//     are re-read; they are L2-resident from the previous steps);
+//   * wave TJ        : halo row, computes only the j-flux of the tile's top face;
+//   * wave TJ+1      : halo column, lane l computes only the i-flux of the
+//     tile's right face for row l.
+// Every flux is therefore evaluated once per face (+ 2/(3 TJ) halo overhead +
+// 1/chunk for the first k-face of a chunk) instead of twice as in the gather
+// form, and all plane accesses of a wave are 512-byte coalesced rows.
+// The residual is still summed per cell in the reference's order
+// (-I_lo +I_up -J_lo +J_up -K_lo +K_up; procBlock.cpp:447-463,6121-6123).
+// With FUSE the kernel also performs procBlock::UpdateBlock (explicit Euler /
+// RK stage, procBlock.cpp:826-947) into the second state buffer and reduces
+// the residual norms, so one launch is one whole mgSolution::Iterate stage
+// and moves the algorithmic 296 B / cell.
+struct MarchArgs {
+  int kchunk;              // k planes per workgroup
+  int mode;                // FUSE: 0 explicit Euler, 1 RK stage
+  double alpha;            // RK stage coefficient
+  NormPartial* partials;   // FUSE: one per workgroup
+};
+
+// Left/right states at the lower d-face of cell qc, reconstructed variable by
+// variable straight from the SoA planes (only the 2x5 face values stay live).
+template <int RECON, int LIM>
+__device__ __forceinline__ void recon_face(const SlabDev& b, int d, long qc,
+                                           long s, double kappa, double* l,
+                                           double* r) {
+  if (RECON == AGX_RECON_CONSTANT) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) { l[e] = b.state(e)[qc - s]; r[e] = b.state(e)[qc]; }
+  } else if (RECON == AGX_RECON_MUSCL) {
+    // FaceReconMUSCL reconstruction.hpp:110-154
+    const double* wd = b.wid(d);
+    const double w2 = wd[qc - 2 * s], w1 = wd[qc - s], w0 = wd[qc], wp = wd[qc + s];
+    const double dPl = (w1 + w1) / (w1 + w0), dMl = (w1 + w1) / (w1 + w2);
+    const double dPr = (w0 + w0) / (w0 + w1), dMr = (w0 + w0) / (w0 + wp);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      const double* p = b.state(e);
+      const double u2 = p[qc - 2 * s], u1 = p[qc - s], u0 = p[qc], up = p[qc + s];
+      l[e] = muscl<LIM>(u2, u1, u0, dPl, dMl, kappa);
+      r[e] = muscl<LIM>(up, u0, u1, dPr, dMr, kappa);
+    }
+  } else {
+    // FaceReconWENO reconstruction.hpp:244-310
+    double w[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) w[m] = b.wid(d)[qc + (m - 3) * s];
+    const double cwl[5] = {w[0], w[1], w[2], w[3], w[4]};
+    const double cwr[5] = {w[5], w[4], w[3], w[2], w[1]};
+    WenoCoeffs kl, kr;
+    weno_coeffs(cwl, kl);
+    weno_coeffs(cwr, kr);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      const double* p = b.state(e);
+      double u[6];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) u[m] = p[qc + (m - 3) * s];
+      l[e] = weno<RECON == AGX_RECON_WENOZ>(kl, cwl, u[0], u[1], u[2], u[3], u[4]);
+      r[e] = weno<RECON == AGX_RECON_WENOZ>(kr, cwr, u[5], u[4], u[3], u[2], u[1]);
+    }
+  }
+}
+// flux through the lower d-face of cell qc, already multiplied by |A|
+template <int RECON, int LIM, int FLUX>
+__device__ __forceinline__ void face_flux_area(const SlabDev& b, const GasDev& g,
+                                               double kappa, int d, long qc,
+                                               long s, const double* area,
+                                               double* f) {
+  double l[AGX_NEQ], r[AGX_NEQ];
+  recon_face<RECON, LIM>(b, d, qc, s, kappa, l, r);
+  inviscid_flux<FLUX>(g, l, r, area, f);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) f[e] *= area[3];
+}
+
+template <int RECON, int LIM, int FLUX, bool FUSE, int TJ>
+__global__ void __launch_bounds__(64 * (TJ + 2))
+k_residual_march(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
+  __shared__ double sFj[2][TJ + 1][AGX_NEQ][64];
+  __shared__ double sFi[2][TJ][AGX_NEQ];
+  const int lane = threadIdx.x, wv = threadIdx.y;
+  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * TJ;
+  const int k0 = blockIdx.z * ma.kchunk;
+  const int k1 = min(k0 + ma.kchunk, b.nk);
+  const int itop = min(i0 + 64, b.ni), jtop = min(j0 + TJ, b.nj);
+  // roles
+  const bool cell_wave = wv < TJ;
+  int i, j;
+  bool cell = false, do_fi = false, do_fj = false;
+  if (cell_wave) {
+    i = i0 + lane; j = j0 + wv;
+    cell = i < itop && j < jtop;
+    do_fi = cell; do_fj = cell;
+  } else if (wv == TJ) {            // halo row: top j-face of the tile
+    i = i0 + lane; j = jtop;
+    do_fj = i < itop;
+  } else {                          // halo column: right i-face of the tile
+    i = itop; j = j0 + lane;
+    do_fi = lane < TJ && j < jtop;
+  }
+  // clamp so that idle lanes still address valid memory
+  const int ic = min(i, b.ni), jc = min(j, b.nj);
+  const long s_i = 1, s_j = b.sx, s_k = b.sxy;
+  long q = b.idx(ic, jc, k0);
+  double fk_lo[AGX_NEQ] = {0, 0, 0, 0, 0}, ak_lo[4] = {0, 0, 0, 0};
+  if (cell) {   // first k-face of the chunk (prologue)
+    b.area(2, q, ak_lo);
+    face_flux_area<RECON, LIM, FLUX>(b, g, sp.kappa, 2, q, s_k, ak_lo, fk_lo);
+  }
+  double l2[AGX_NEQ] = {0, 0, 0, 0, 0};
+  double vmax = -1.0e300;
+  long long vlin = 0x7fffffffffffffffLL;
+  int buf = 0;
+  for (int k = k0; k < k1; ++k, q += s_k, buf ^= 1) {
+    double fi[AGX_NEQ] = {0, 0, 0, 0, 0}, fj[AGX_NEQ] = {0, 0, 0, 0, 0};
+    double fk_up[AGX_NEQ], ai_lo[4], aj_lo[4], ak_up[4];
+    if (do_fi) {
+      b.area(0, q, ai_lo);
+      face_flux_area<RECON, LIM, FLUX>(b, g, sp.kappa, 0, q, s_i, ai_lo, fi);
+    }
+    if (do_fj) {
+      b.area(1, q, aj_lo);
+      face_flux_area<RECON, LIM, FLUX>(b, g, sp.kappa, 1, q, s_j, aj_lo, fj);
+    }
+    if (cell) {
+      b.area(2, q + s_k, ak_up);
+      face_flux_area<RECON, LIM, FLUX>(b, g, sp.kappa, 2, q + s_k, s_k, ak_up, fk_up);
+    }
+    // publish the fluxes the neighbours need
+    if (wv <= TJ) {
+      const int row = cell_wave ? wv : (jtop - j0);
+      if (do_fj) {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) sFj[buf][row][e][lane] = fj[e];
+      }
+    } else if (do_fi) {
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) sFi[buf][lane][e] = fi[e];
+    }
+    __syncthreads();
+    if (cell_wave) {
+      double fi_up[AGX_NEQ];
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) fi_up[e] = __shfl_down(fi[e], 1, 64);
+      if (cell) {
+        if (i == itop - 1) {
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) fi_up[e] = sFi[buf][wv][e];
+        }
+        double res[AGX_NEQ];
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e)
+          res[e] = ((((-fi[e] + fi_up[e]) - fj[e]) + sFj[buf][wv + 1][e][lane]) -
+                    fk_lo[e]) + fk_up[e];
+        // InvCellSpectralRadius spectralRadius.hpp:44-64, three directions
+        double sc[AGX_NEQ];
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) sc[e] = b.state(e)[q];
+        const double cs = sound_speed(g, sc);
+        double sr = 0.0;
+        {
+          double au[4];
+          b.area(0, q + s_i, au);
+          double v[3] = {0.5 * (ai_lo[0] + au[0]), 0.5 * (ai_lo[1] + au[1]), 0.5 * (ai_lo[2] + au[2])};
+          sr += (fabs(dot3(sc + 1, v)) * rsqrt(dot3(v, v)) + cs) * (0.5 * (ai_lo[3] + au[3]));
+          b.area(1, q + s_j, au);
+          v[0] = 0.5 * (aj_lo[0] + au[0]); v[1] = 0.5 * (aj_lo[1] + au[1]); v[2] = 0.5 * (aj_lo[2] + au[2]);
+          sr += (fabs(dot3(sc + 1, v)) * rsqrt(dot3(v, v)) + cs) * (0.5 * (aj_lo[3] + au[3]));
+          v[0] = 0.5 * (ak_lo[0] + ak_up[0]); v[1] = 0.5 * (ak_lo[1] + ak_up[1]); v[2] = 0.5 * (ak_lo[2] + ak_up[2]);
+          sr += (fabs(dot3(sc + 1, v)) * rsqrt(dot3(v, v)) + cs) * (0.5 * (ak_lo[3] + ak_up[3]));
+        }
+        const double vol = b.pl(PL_VOL)[q];
+        const double dt = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (vol / fmax(sr, 0.0));
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) b.pl(PL_RESID + e)[q] = res[e];
+        b.pl(PL_SPECRAD)[q] = sr;
+        if (sp.implicit) b.pl(PL_A)[q] = sr;
+        if (!sp.viscous) b.pl(PL_DT)[q] = dt;
+        if (FUSE) {
+          double u[AGX_NEQ], ns[AGX_NEQ];
+          double fac = dt / vol;
+          if (ma.mode == 0) {
+            prim_to_cons(g, sc, u);
+          } else {
+#pragma unroll
+            for (int e = 0; e < AGX_NEQ; ++e) u[e] = b.pl(PL_CONSN + e)[q];
+            fac *= ma.alpha;
+          }
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) u[e] -= fac * res[e];
+          cons_to_prim(g, u, ns);
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) b.snew(e)[q] = ns[e];
+          const long lin0 = (((long)k * b.nj + j) * b.ni + i) * AGX_NEQ;
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) {
+            l2[e] += res[e] * res[e];
+            if (res[e] > vmax) { vmax = res[e]; vlin = lin0 + e; }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) fk_lo[e] = fk_up[e];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ak_lo[c] = ak_up[c];
+      }
+    }
+  }
+  if (FUSE) {
+    // workgroup reduction of the norm partials (TJ + 2 waves)
+    constexpr int NW = TJ + 2;
+    __shared__ double shv[AGX_NEQ + 1][NW];
+    __shared__ long long shl[NW];
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) l2[e] += __shfl_down(l2[e], off, 64);
+      const double ov = __shfl_down(vmax, off, 64);
+      const long long ol = __shfl_down(vlin, off, 64);
+      if (ov > vmax || (ov == vmax && ol < vlin)) { vmax = ov; vlin = ol; }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) shv[e][wv] = l2[e];
+      shv[AGX_NEQ][wv] = vmax;
+      shl[wv] = vlin;
+    }
+    __syncthreads();
+    if (lane == 0 && wv == 0) {
+      NormPartial p;
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) {
+        double acc = 0.0;
+        for (int w = 0; w < NW; ++w) acc += shv[e][w];
+        p.l2[e] = acc;
+      }
+      p.vmax = shv[AGX_NEQ][0];
+      p.lin = shl[0];
+      for (int w = 1; w < NW; ++w)
+        if (shv[AGX_NEQ][w] > p.vmax || (shv[AGX_NEQ][w] == p.vmax && shl[w] < p.lin)) {
+          p.vmax = shv[AGX_NEQ][w];
+          p.lin = shl[w];
+        }
+      const long bid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      ma.partials[bid] = p;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -465,7 +758,6 @@ __global__ void k_halo_scatter(Planes5 a, const long* __restrict__ dst, long n,
 // ImplicitTimeAdvance :902).  Norm partials: per-block sums of r^2 per
 // equation and the signed max residual with its first (k,j,i,eqn) location;
 // a second kernel folds the partials in a fixed order (reproducible).
-struct NormPartial { double l2[AGX_NEQ]; double vmax; long long lin; };
 
 __device__ __forceinline__ void norm_block_reduce(const double* r, long lin0,
                                                   bool active,

@@ -215,7 +215,7 @@ class PhasedSolver(Solver):
         api.check(api.phase_bc_faces(ctx), "phase_bc_faces")
         self._halo(abi.HALO_STATE)
         api.check(api.phase_bc_edges(ctx), "phase_bc_edges")
-        api.check(api.phase_residual(ctx, cfl), "phase_residual")
+        api.check(api.phase_residual(ctx, mm, cfl), "phase_residual")
         if self.case.deck.is_implicit():
             api.check(api.phase_implicit_begin(ctx), "phase_implicit_begin")
             lusgs = cfg.matrix_solver == abi.SOLVER["lusgs"]

@@ -220,7 +220,9 @@ int agx_iterate(agx_ctx *ctx, int mm, double cfl, double *l2, agx_linf *linf,
  *                    [halo UPDATE], matrix_residual, implicit_update          */
 int agx_phase_bc_faces(agx_ctx *ctx);          /* AssignInviscidGhostCells  procBlock.cpp:2449 */
 int agx_phase_bc_edges(agx_ctx *ctx);          /* AssignInviscidGhostCellsEdge procBlock.cpp:2565 */
-int agx_phase_residual(agx_ctx *ctx, double cfl); /* CalcResidualNoSource :6111 + CalcBlockTimeStep :798 */
+/* mm: nonlinear iteration (RK stage) -- explicit inviscid runs fuse the stage
+ * update into the residual kernel, explicit_update then only swaps buffers */
+int agx_phase_residual(agx_ctx *ctx, int mm, double cfl); /* CalcResidualNoSource :6111 + CalcBlockTimeStep :798 */
 int agx_phase_explicit_update(agx_ctx *ctx, int mm, double *l2, agx_linf *linf); /* UpdateBlock :826 */
 int agx_phase_implicit_begin(agx_ctx *ctx);    /* InvertDiagonal + InitializeMatrixUpdate mgSolution.cpp:225-229 */
 int agx_phase_relax_forward(agx_ctx *ctx, int sweep);  /* LUSGS_Forward :341 / DPLUR :473 */

@@ -1680,7 +1680,8 @@ int ora_phase_bc_edges(ora_ctx *c) {
     if (assign_ghost_edges(c, &c->blk[n], 0)) return 1;
   return 0;
 }
-int ora_phase_residual(ora_ctx *c, double cfl) {
+int ora_phase_residual(ora_ctx *c, int mm, double cfl) {
+  (void)mm;
   for (int n = 0; n < c->nblk; ++n) {
     if (calc_residual(c, &c->blk[n])) return 1;
   }
@@ -1802,7 +1803,7 @@ int ora_iterate(ora_ctx *c, int mm, double cfl, double *l2, agx_linf *linf,
   if (ora_phase_bc_faces(c)) return 1;
   if (ora_halo_swap_local(c, AGX_HALO_STATE)) return 1;
   if (ora_phase_bc_edges(c)) return 1;
-  if (ora_phase_residual(c, cfl)) return 1;
+  if (ora_phase_residual(c, mm, cfl)) return 1;
   *matrix_resid = 0.0;
   if (c->cfg.time_integration >= AGX_TIME_IMPLICIT_EULER) {
     ora_phase_implicit_begin(c);

@@ -40,7 +40,7 @@ int ora_iterate(ora_ctx *ctx, int mm, double cfl, double *l2, agx_linf *linf,
                 double *matrix_resid);
 int ora_phase_bc_faces(ora_ctx *ctx);
 int ora_phase_bc_edges(ora_ctx *ctx);
-int ora_phase_residual(ora_ctx *ctx, double cfl);
+int ora_phase_residual(ora_ctx *ctx, int mm, double cfl);
 int ora_phase_explicit_update(ora_ctx *ctx, int mm, double *l2, agx_linf *linf);
 int ora_phase_implicit_begin(ora_ctx *ctx);
 int ora_phase_relax_forward(ora_ctx *ctx, int sweep);
