@@ -78,7 +78,8 @@ struct agx_ctx {
   int* err_host = nullptr;              // pinned
   double* halo_buf = nullptr;
   long halo_cap = 0;
-  bool use_gather = false;   // AGX_GATHER=1: one-thread-per-cell gather kernel
+  bool use_gather = false;   // AGX_KERNEL=gather: one-thread-per-cell gather kernel
+  bool use_tile = true;      // AGX_KERNEL=tile (default) | march
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
   long fused_parts = 0;
@@ -136,6 +137,7 @@ int derive_gas(const agx_config& cfg, GasDev& g) {
   const agx_gas& a = cfg.gas;
   g.R = a.gas_constant;
   g.n = a.n;
+  g.inv_n = 1.0 / a.n;
   g.hf = a.heat_of_formation;
   g.cp = a.gas_constant * (a.n + 1.0);   // thermodynamic.hpp:108-113
   g.cv = a.gas_constant * a.n;
@@ -287,12 +289,12 @@ int check_device_error(agx_ctx* c) {
 }
 
 struct MarchPlan { dim3 grid; int kchunk; long nparts; };
-int g_march_tj = 6;   // rows per workgroup: 6 (512 threads) or 14 (1024 threads)
+int g_march_tj = 6;   // cell rows per workgroup (512 threads)
 MarchPlan march_plan(const BlockDev& b) {
   MarchPlan p;
   const int gx = (b.ni + 63) / 64, gy = (b.nj + g_march_tj - 1) / g_march_tj;
   // aim at >= ~2048 workgroups so that all 256 CUs stay busy to the end
-  int nz = std::max(1, (int)std::lround((g_march_tj == 14 ? 1024.0 : 2048.0) / (gx * gy)));
+  int nz = std::max(1, (int)std::lround(2048.0 / (gx * gy)));
   nz = std::min(nz, std::max(1, b.nk / 4));
   p.kchunk = (b.nk + nz - 1) / nz;
   nz = (b.nk + p.kchunk - 1) / p.kchunk;
@@ -316,12 +318,12 @@ void launch_inv_kernel(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
     return;
   }
   const dim3 tb(64, g_march_tj + 2);
-  if (g_march_tj == 14) {
+  if (c->use_tile) {
     if (fuse)
-      hipLaunchKernelGGL((k_residual_march<RECON, LIM, FLUX, true, 14>), mp.grid, tb, 0,
+      hipLaunchKernelGGL((k_residual_tile<RECON, LIM, FLUX, true, 6>), mp.grid, tb, 0,
                          c->stream, sd, c->gas, c->sp, cfl, ma);
     else
-      hipLaunchKernelGGL((k_residual_march<RECON, LIM, FLUX, false, 14>), mp.grid, tb, 0,
+      hipLaunchKernelGGL((k_residual_tile<RECON, LIM, FLUX, false, 6>), mp.grid, tb, 0,
                          c->stream, sd, c->gas, c->sp, cfl, ma);
   } else {
     if (fuse)
@@ -468,9 +470,11 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
   agx_ctx* c = new agx_ctx();
   c->device = device;
   c->rank = rank;
-  c->use_gather = getenv("AGX_GATHER") && atoi(getenv("AGX_GATHER")) != 0;
+  if (const char* kn = getenv("AGX_KERNEL")) {
+    c->use_gather = !strcmp(kn, "gather");
+    c->use_tile = !strcmp(kn, "tile");
+  }
   c->allow_fuse = !(getenv("AGX_NO_FUSE") && atoi(getenv("AGX_NO_FUSE")) != 0);
-  if (getenv("AGX_TJ")) g_march_tj = atoi(getenv("AGX_TJ")) == 14 ? 14 : 6;
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
   HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
   HIPCHK(hipHostMalloc((void**)&c->err_host, sizeof(int)));
@@ -737,6 +741,7 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
       const double rk_alpha[4] = {0.25, 1.0 / 3.0, 0.5, 1.0};   // procBlock.cpp:938
       ma.alpha = rk_alpha[mm & 3];
       ma.partials = c->partials + off;
+      ma.ablate = getenv("AGX_ABLATE") ? atoi(getenv("AGX_ABLATE")) : 0;
       launch_inv(c, blk.d, cfl, fuse, ma, mp);
       off += mp.nparts;
     }

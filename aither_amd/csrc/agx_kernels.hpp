@@ -211,6 +211,10 @@ struct MarchArgs {
   int kchunk;              // k planes per workgroup
   int mode;                // FUSE: 0 explicit Euler, 1 RK stage
   double alpha;            // RK stage coefficient
+  int ablate;              // diagnostic (AGX_ABLATE): 1 no flux math, 2 no
+                           // reconstruction, 4 no stores, 8 no cons->prim,
+                           // 16 no spectral radius, 32 idle halo waves,
+                           // 64 no tile publish, 128 no prefetch loads
   NormPartial* partials;   // FUSE: one per workgroup
 };
 
@@ -227,8 +231,9 @@ __device__ __forceinline__ void recon_face(const SlabDev& b, int d, long qc,
     // FaceReconMUSCL reconstruction.hpp:110-154
     const double* wd = b.wid(d);
     const double w2 = wd[qc - 2 * s], w1 = wd[qc - s], w0 = wd[qc], wp = wd[qc + s];
-    const double dPl = (w1 + w1) / (w1 + w0), dMl = (w1 + w1) / (w1 + w2);
-    const double dPr = (w0 + w0) / (w0 + w1), dMr = (w0 + w0) / (w0 + wp);
+    const double r10 = fast_rcp(w1 + w0);
+    const double dPl = (w1 + w1) * r10, dMl = (w1 + w1) * fast_rcp(w1 + w2);
+    const double dPr = (w0 + w0) * r10, dMr = (w0 + w0) * fast_rcp(w0 + wp);
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) {
       const double* p = b.state(e);
@@ -438,6 +443,479 @@ k_residual_march(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         }
       const long bid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       ma.partials[bid] = p;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Inviscid residual, tiled marching form with LDS-staged planes (production).
+//
+// Same face-once decomposition as k_residual_march (one wave per i-row of 64
+// cells, shuffle hand-off in i, LDS hand-off in j, register hand-off in k,
+// two halo waves), plus the classic 2.5-D blocking so that every state value
+// is fetched from HBM once per workgroup:
+//   * each lane keeps the k-stencil of its own column in a rolling register
+//     window; the cell entering the window is loaded ONE STEP AHEAD, so its
+//     HBM latency overlaps a whole step of flux arithmetic;
+//   * the current k-plane of the tile (5 state variables + the i/j cell widths,
+//     with a halo of H cells in i and j) lives in LDS, double buffered: the
+//     interior comes from the register windows, the halo ring is prefetched
+//     from global memory one step ahead; all i/j stencil reads are LDS reads;
+//   * one workgroup barrier per k-step publishes both the j-fluxes and the
+//     next plane.
+template <int RECON, int LIM, class Get, class GetW>
+__device__ __forceinline__ void recon_generic(Get get, GetW getw, double kappa,
+                                              double* l, double* r) {
+  // get(e, m): variable e at stencil offset m from the face (m = -1: left
+  // cell, m = 0: right cell); getw(m): cell width at that offset
+  if (RECON == AGX_RECON_CONSTANT) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) { l[e] = get(e, -1); r[e] = get(e, 0); }
+  } else if (RECON == AGX_RECON_MUSCL) {
+    const double w2 = getw(-2), w1 = getw(-1), w0 = getw(0), wp = getw(1);
+    const double r10 = fast_rcp(w1 + w0);
+    const double dPl = (w1 + w1) * r10, dMl = (w1 + w1) * fast_rcp(w1 + w2);
+    const double dPr = (w0 + w0) * r10, dMr = (w0 + w0) * fast_rcp(w0 + wp);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      const double u2 = get(e, -2), u1 = get(e, -1), u0 = get(e, 0), up = get(e, 1);
+      l[e] = muscl<LIM>(u2, u1, u0, dPl, dMl, kappa);
+      r[e] = muscl<LIM>(up, u0, u1, dPr, dMr, kappa);
+    }
+  } else {
+    double w[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) w[m] = getw(m - 3);
+    const double cwl[5] = {w[0], w[1], w[2], w[3], w[4]};
+    const double cwr[5] = {w[5], w[4], w[3], w[2], w[1]};
+    WenoCoeffs kl, kr;
+    weno_coeffs(cwl, kl);
+    weno_coeffs(cwr, kr);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      double u[6];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) u[m] = get(e, m - 3);
+      l[e] = weno<RECON == AGX_RECON_WENOZ>(kl, cwl, u[0], u[1], u[2], u[3], u[4]);
+      r[e] = weno<RECON == AGX_RECON_WENOZ>(kr, cwr, u[5], u[4], u[3], u[2], u[1]);
+    }
+  }
+}
+
+template <int RECON, int LIM, int FLUX, bool FUSE, int TJ>
+__global__ void __launch_bounds__(64 * (TJ + 2))
+k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
+  constexpr int H = RECON == AGX_RECON_CONSTANT ? 1
+                    : (RECON == AGX_RECON_MUSCL ? 2 : 3);
+  constexpr int NV = AGX_NEQ + 2;                 // state + wid_i + wid_j
+  constexpr int TW = 64 + 2 * H, TR = TJ + 2 * H;
+  constexpr int NW = TJ + 2;
+  constexpr int PLANE = TR * TW;                  // doubles per variable
+  __shared__ double tile[2][NV][TR][TW];
+  __shared__ double sFj[2][TJ + 1][AGX_NEQ][64];  // lower j-face fluxes
+  __shared__ double sFi[2][TJ][AGX_NEQ];          // right-face i-fluxes (halo wave)
+  // per-thread slots of the cell waves: norm accumulators, and (MUSCL and
+  // below, where LDS allows) the lower k-face flux / area carried between steps
+  constexpr bool PARK = H <= 2;
+  __shared__ double sNorm[AGX_NEQ + 1][TJ][64];
+  __shared__ long long sLin[TJ][64];
+  __shared__ double sFk[PARK ? TJ : 1][AGX_NEQ][64];
+  __shared__ double sAk[PARK ? TJ : 1][4][64];
+  const int lane = threadIdx.x, wv = threadIdx.y;
+  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * TJ;
+  const int k0 = blockIdx.z * ma.kchunk;
+  const int k1 = min(k0 + ma.kchunk, b.nk);
+  const int itop = min(i0 + 64, b.ni), jtop = min(j0 + TJ, b.nj);
+  const long s_k = b.sxy;
+  if (FUSE && wv < TJ) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) sNorm[e][wv][lane] = 0.0;
+    sNorm[AGX_NEQ][wv][lane] = -1.0e300;
+    sLin[wv][lane] = 0x7fffffffffffffffLL;
+  }
+  if (wv < TJ) {
+    // ======================= cell waves =====================================
+    const int i = i0 + lane, j = j0 + wv;
+    const bool cell = i < itop && j < jtop;
+    const int ic = min(i, b.ni + b.ng - 1), jc = min(j, b.nj + b.ng - 1);
+    long q = b.idx(ic, jc, k0);
+    const int to = (wv + H) * TW + lane + H;      // own slot in a tile plane
+    const int pw = PARK ? wv : 0;
+    double W[2 * H][AGX_NEQ], wk[2 * H];
+    double fk_reg[AGX_NEQ] = {0, 0, 0, 0, 0}, ak_reg[4];   // !PARK only
+    {
+      double W0[AGX_NEQ], w0, ak_lo[4], fk_lo[AGX_NEQ] = {0, 0, 0, 0, 0};
+      b.area(2, q, ak_lo);
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) W0[e] = b.state(e)[q - H * s_k];
+      w0 = b.wid(2)[q - H * s_k];
+#pragma unroll
+      for (int m = 0; m < 2 * H; ++m) {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) W[m][e] = b.state(e)[q + (m - H + 1) * s_k];
+        wk[m] = b.wid(2)[q + (m - H + 1) * s_k];
+      }
+      if (cell) {
+        double l[AGX_NEQ], r[AGX_NEQ];
+        recon_generic<RECON, LIM>(
+            [&](int e, int m) { return m + H == 0 ? W0[e] : W[m + H - 1][e]; },
+            [&](int m) { return m + H == 0 ? w0 : wk[m + H - 1]; }, sp.kappa, l, r);
+        inviscid_flux<FLUX>(g, l, r, ak_lo, fk_lo);
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) fk_lo[e] *= ak_lo[3];
+      }
+      if (PARK) {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) sFk[pw][e][lane] = fk_lo[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sAk[pw][e][lane] = ak_lo[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) fk_reg[e] = fk_lo[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ak_reg[e] = ak_lo[e];
+      }
+      double* tl = &tile[0][0][0][0];
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) tl[e * PLANE + to] = W[H - 1][e];
+      tl[AGX_NEQ * PLANE + to] = b.wid(0)[q];
+      tl[(AGX_NEQ + 1) * PLANE + to] = b.wid(1)[q];
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k = k0; k < k1; ++k, q += s_k, cur ^= 1) {
+      const double* tc = &tile[cur][0][0][0];
+      double* tn = &tile[cur ^ 1][0][0][0];
+      // the load needed first is issued first (vmcnt retires in order), the
+      // next-step prefetch after it
+      double ak_up[4];
+      b.area(2, q + s_k, ak_up);
+      double nxt[AGX_NEQ], nwk, nwi, nwj;
+      if (ma.ablate & 128) {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) nxt[e] = W[2 * H - 1][e];
+        nwk = wk[0]; nwi = wk[0]; nwj = wk[0];
+      } else {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) nxt[e] = b.state(e)[q + (H + 1) * s_k];
+        nwk = b.wid(2)[q + (H + 1) * s_k];
+        nwi = b.wid(0)[q + s_k];
+        nwj = b.wid(1)[q + s_k];
+      }
+      // InvCellSpectralRadius spectralRadius.hpp:44-64, one direction per block
+      const double* sc = W[H - 1];
+      const double cs = sound_speed(g, sc);
+      auto specrad = [&](const double* al, const double* au) {
+        const double v[3] = {0.5 * (al[0] + au[0]), 0.5 * (al[1] + au[1]),
+                             0.5 * (al[2] + au[2])};
+        return (fabs(dot3(sc + 1, v)) * fast_rsqrt(dot3(v, v)) + cs) * (0.5 * (al[3] + au[3]));
+      };
+      double res[AGX_NEQ] = {0, 0, 0, 0, 0};
+      double sr_i = 0.0, sr_j = 0.0, sr_k = 0.0;
+      // ---- k face (upper): stencil from the register window ----
+      if (cell) {
+        double l[AGX_NEQ], r[AGX_NEQ], f[AGX_NEQ];
+        if (ma.ablate & 2) {
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) { l[e] = W[H - 1][e]; r[e] = W[H][e]; }
+        } else {
+          recon_generic<RECON, LIM>([&](int e, int m) { return W[m + H][e]; },
+                                    [&](int m) { return wk[m + H]; }, sp.kappa, l, r);
+        }
+        if (ma.ablate & 1) {
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) f[e] = l[e] + r[e] * ak_up[0];
+        } else {
+          inviscid_flux<FLUX>(g, l, r, ak_up, f);
+        }
+        double ak_lo[4];
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) {
+          f[e] *= ak_up[3];
+          if (PARK) {
+            res[e] = f[e] - sFk[pw][e][lane];
+            sFk[pw][e][lane] = f[e];
+          } else {
+            res[e] = f[e] - fk_reg[e];
+            fk_reg[e] = f[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (PARK) {
+            ak_lo[e] = sAk[pw][e][lane];
+            sAk[pw][e][lane] = ak_up[e];
+          } else {
+            ak_lo[e] = ak_reg[e];
+            ak_reg[e] = ak_up[e];
+          }
+        }
+        sr_k = (ma.ablate & 16) ? 1.0 : specrad(ak_lo, ak_up);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- i face (lower): stencil from the LDS plane; the upper face comes
+      // from lane + 1 (the tile's right face from the halo wave, below) ----
+      {
+        double fi[AGX_NEQ] = {0, 0, 0, 0, 0};
+        if (cell) {
+          double l[AGX_NEQ], r[AGX_NEQ], ai_lo[4], ai_up[4];
+          b.area(0, q, ai_lo);
+          b.area(0, q + 1, ai_up);
+          const double* base = tc + to;
+          if (ma.ablate & 2) {
+#pragma unroll
+            for (int e = 0; e < AGX_NEQ; ++e) { l[e] = base[e * PLANE - 1]; r[e] = base[e * PLANE]; }
+          } else {
+            recon_generic<RECON, LIM>(
+                [&](int e, int m) { return base[e * PLANE + m]; },
+                [&](int m) { return base[AGX_NEQ * PLANE + m]; }, sp.kappa, l, r);
+          }
+          if (ma.ablate & 1) {
+#pragma unroll
+            for (int e = 0; e < AGX_NEQ; ++e) fi[e] = l[e] + r[e] * ai_lo[0];
+          } else {
+            inviscid_flux<FLUX>(g, l, r, ai_lo, fi);
+          }
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) fi[e] *= ai_lo[3];
+          sr_i = (ma.ablate & 16) ? 1.0 : specrad(ai_lo, ai_up);
+        }
+        const bool edge = i == itop - 1;
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) {
+          const double up = __shfl_down(fi[e], 1, 64);
+          res[e] += (edge ? 0.0 : up) - fi[e];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- j face (lower): handed to the row below through LDS ----
+      if (cell) {
+        double l[AGX_NEQ], r[AGX_NEQ], f[AGX_NEQ], aj_lo[4], aj_up[4];
+        b.area(1, q, aj_lo);
+        b.area(1, q + b.sx, aj_up);
+        const double* base = tc + to;
+        if (ma.ablate & 2) {
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) { l[e] = base[e * PLANE - TW]; r[e] = base[e * PLANE]; }
+        } else {
+          recon_generic<RECON, LIM>(
+              [&](int e, int m) { return base[e * PLANE + m * TW]; },
+              [&](int m) { return base[(AGX_NEQ + 1) * PLANE + m * TW]; }, sp.kappa, l, r);
+        }
+        if (ma.ablate & 1) {
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) f[e] = l[e] + r[e] * aj_lo[0];
+        } else {
+          inviscid_flux<FLUX>(g, l, r, aj_lo, f);
+        }
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) {
+          f[e] *= aj_lo[3];
+          sFj[cur][wv][e][lane] = f[e];
+          res[e] -= f[e];
+        }
+        sr_j = (ma.ablate & 16) ? 1.0 : specrad(aj_lo, aj_up);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // publish the own entry of the next plane; the loads of the update fly
+      // across the barrier
+      if (!(ma.ablate & 64)) {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) tn[e * PLANE + to] = W[H][e];
+        tn[AGX_NEQ * PLANE + to] = nwi;
+        tn[(AGX_NEQ + 1) * PLANE + to] = nwj;
+      }
+      const double vol = b.pl(PL_VOL)[q];
+      double cn[AGX_NEQ];
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e)
+        cn[e] = (FUSE && ma.mode != 0) ? b.pl(PL_CONSN + e)[q] : 0.0;
+      __syncthreads();
+      if (cell) {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) res[e] += sFj[cur][wv + 1][e][lane];
+        if (i == itop - 1) {
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) res[e] += sFi[cur][wv][e];
+        }
+        const double sr = (sr_i + sr_j) + sr_k;
+        const double dt = sp.dt_fixed > 0.0 ? sp.dt_fixed
+                                            : cfl * (vol * fast_rcp(fmax(sr, 0.0)));
+        const bool st_ok = !(ma.ablate & 4) || res[0] == 12345.678;
+        if (st_ok) {
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) b.pl(PL_RESID + e)[q] = res[e];
+          b.pl(PL_SPECRAD)[q] = sr;
+          if (sp.implicit) b.pl(PL_A)[q] = sr;
+          if (!sp.viscous) b.pl(PL_DT)[q] = dt;
+        }
+        if (FUSE) {
+          double u[AGX_NEQ], ns[AGX_NEQ];
+          double fac = dt * fast_rcp(vol);
+          if (ma.mode == 0) {
+            prim_to_cons(g, sc, u);
+          } else {
+#pragma unroll
+            for (int e = 0; e < AGX_NEQ; ++e) u[e] = cn[e];
+            fac *= ma.alpha;
+          }
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) u[e] -= fac * res[e];
+          if (ma.ablate & 8) {
+#pragma unroll
+            for (int e = 0; e < AGX_NEQ; ++e) ns[e] = u[e];
+          } else {
+            cons_to_prim(g, u, ns);
+          }
+          if (st_ok) {
+#pragma unroll
+            for (int e = 0; e < AGX_NEQ; ++e) b.snew(e)[q] = ns[e];
+          }
+          const long lin0 = (((long)k * b.nj + j) * b.ni + i) * AGX_NEQ;
+          double vm = sNorm[AGX_NEQ][wv][lane];
+          long long vl = sLin[wv][lane];
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) {
+            sNorm[e][wv][lane] += res[e] * res[e];
+            if (res[e] > vm) { vm = res[e]; vl = lin0 + e; }
+          }
+          sNorm[AGX_NEQ][wv][lane] = vm;
+          sLin[wv][lane] = vl;
+        }
+      }
+      // advance the k window
+#pragma unroll
+      for (int m = 0; m < 2 * H - 1; ++m) {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) W[m][e] = W[m + 1][e];
+        wk[m] = wk[m + 1];
+      }
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) W[2 * H - 1][e] = nxt[e];
+      wk[2 * H - 1] = nwk;
+    }
+  } else {
+    // ======================= halo waves =======================================
+    // wave TJ  : j-flux of the tile's top face + upper halo rows of the tile
+    // wave TJ+1: i-flux of the tile's right face + lower halo rows + halo columns
+    const bool top = wv == TJ;
+    const int gi = min(i0 + lane, b.ni + b.ng - 1);
+    long qrow[H];            // global offsets (k = 0) of this wave's halo rows
+    int lrow[H];
+#pragma unroll
+    for (int m = 0; m < H; ++m) {
+      const int row = top ? TJ + H + m : m;
+      const int gj = min(max(j0 - H + row, -b.ng), b.nj + b.ng - 1);
+      qrow[m] = b.idx(gi, gj, 0);
+      lrow[m] = row * TW + lane + H;
+    }
+    // halo columns (wave TJ+1 only): lane -> (row, column)
+    const bool hc = !top && lane < 2 * H * TJ;
+    const int cc = lane % (2 * H), crow = H + min(lane / (2 * H), TJ - 1);
+    const int ccol = cc < H ? cc : 64 + cc;
+    const long qcol = b.idx(min(max(i0 - H + ccol, -b.ng), b.ni + b.ng - 1),
+                            min(j0 - H + crow, b.nj + b.ng - 1), 0);
+    const int lcol = crow * TW + ccol;
+    // flux duty
+    bool do_f;
+    long qf;
+    int fo;                  // stencil origin in the tile plane
+    if (top) {
+      do_f = i0 + lane < itop;
+      qf = b.idx(min(i0 + lane, b.ni), jtop, 0);
+      fo = (jtop - j0 + H) * TW + lane + H;
+    } else {
+      do_f = lane < TJ && j0 + lane < jtop;
+      qf = b.idx(itop, min(j0 + lane, b.nj), 0);
+      fo = (min(lane, TJ - 1) + H) * TW + (itop - i0) + H;
+    }
+    {
+      double* tl = &tile[0][0][0][0];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const double* p = b.pl(v < AGX_NEQ ? b.st + v : PL_WID + (v - AGX_NEQ));
+#pragma unroll
+        for (int m = 0; m < H; ++m) tl[v * PLANE + lrow[m]] = p[qrow[m] + (long)k0 * s_k];
+        if (hc) tl[v * PLANE + lcol] = p[qcol + (long)k0 * s_k];
+      }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k = k0; k < k1; ++k, cur ^= 1) {
+      const double* tc = &tile[cur][0][0][0];
+      double* tn = &tile[cur ^ 1][0][0][0];
+      double af[4] = {0, 0, 0, 1};
+      if (ma.ablate & 32) { __syncthreads(); continue; }
+      if (do_f) b.area(top ? 1 : 0, qf + (long)k * s_k, af);
+      // prefetch the halo ring of plane k+1
+      double hv[NV][H], hcv[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const double* p = b.pl(v < AGX_NEQ ? b.st + v : PL_WID + (v - AGX_NEQ));
+#pragma unroll
+        for (int m = 0; m < H; ++m) hv[v][m] = p[qrow[m] + (long)(k + 1) * s_k];
+        hcv[v] = hc ? p[qcol + (long)(k + 1) * s_k] : 0.0;
+      }
+      if (do_f) {
+        double l[AGX_NEQ], r[AGX_NEQ], f[AGX_NEQ];
+        const double* base = tc + fo;
+        if (top) {
+          recon_generic<RECON, LIM>(
+              [&](int e, int m) { return base[e * PLANE + m * TW]; },
+              [&](int m) { return base[(AGX_NEQ + 1) * PLANE + m * TW]; }, sp.kappa, l, r);
+          inviscid_flux<FLUX>(g, l, r, af, f);
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) sFj[cur][jtop - j0][e][lane] = f[e] * af[3];
+        } else {
+          recon_generic<RECON, LIM>(
+              [&](int e, int m) { return base[e * PLANE + m]; },
+              [&](int m) { return base[AGX_NEQ * PLANE + m]; }, sp.kappa, l, r);
+          inviscid_flux<FLUX>(g, l, r, af, f);
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) sFi[cur][lane][e] = f[e] * af[3];
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int m = 0; m < H; ++m) tn[v * PLANE + lrow[m]] = hv[v][m];
+        if (hc) tn[v * PLANE + lcol] = hcv[v];
+      }
+      __syncthreads();
+    }
+  }
+  if (FUSE) {
+    __syncthreads();
+    // fold the per-thread accumulators: wave 0 sums over the waves, then lanes
+    if (wv == 0) {
+      double l2[AGX_NEQ];
+      double vmax = -1.0e300;
+      long long vlin = 0x7fffffffffffffffLL;
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) l2[e] = 0.0;
+      for (int w = 0; w < TJ; ++w) {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) l2[e] += sNorm[e][w][lane];
+        const double ov = sNorm[AGX_NEQ][w][lane];
+        const long long ol = sLin[w][lane];
+        if (ov > vmax || (ov == vmax && ol < vlin)) { vmax = ov; vlin = ol; }
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) l2[e] += __shfl_down(l2[e], off, 64);
+        const double ov = __shfl_down(vmax, off, 64);
+        const long long ol = __shfl_down(vlin, off, 64);
+        if (ov > vmax || (ov == vmax && ol < vlin)) { vmax = ov; vlin = ol; }
+      }
+      if (lane == 0) {
+        NormPartial p;
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) p.l2[e] = l2[e];
+        p.vmax = vmax;
+        p.lin = vlin;
+        const long bid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        ma.partials[bid] = p;
+      }
     }
   }
 }
