@@ -80,6 +80,7 @@ struct agx_ctx {
   long halo_cap = 0;
   bool use_gather = false;   // AGX_KERNEL=gather: one-thread-per-cell gather kernel
   bool use_tile = true;      // AGX_KERNEL=tile (default) | march
+  int num_cu = 256;          // persistent workgroups of the tile kernel
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
   long fused_parts = 0;
@@ -290,9 +291,20 @@ int check_device_error(agx_ctx* c) {
 
 struct MarchPlan { dim3 grid; int kchunk; long nparts; };
 int g_march_tj = 6;   // cell rows per workgroup (512 threads)
-MarchPlan march_plan(const BlockDev& b) {
+MarchPlan march_plan(const agx_ctx* c, const BlockDev& b) {
   MarchPlan p;
   const int gx = (b.ni + 63) / 64, gy = (b.nj + g_march_tj - 1) / g_march_tj;
+  if (c->use_tile && !c->use_gather) {
+    // persistent workgroups, one per CU (LDS allows no more); small blocks get
+    // fewer so that a range is at least ~8 steps long
+    const long steps = (long)gx * gy * b.nk;
+    long np = std::min<long>(c->num_cu, std::max<long>(1, steps / 8));
+    if (np >= 8) np -= np % 8;
+    p.kchunk = 0;
+    p.grid = dim3((unsigned)np);
+    p.nparts = np;
+    return p;
+  }
   // aim at >= ~2048 workgroups so that all 256 CUs stay busy to the end
   int nz = std::max(1, (int)std::lround(2048.0 / (gx * gy)));
   nz = std::min(nz, std::max(1, b.nk / 4));
@@ -407,7 +419,7 @@ int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
     long off = 0;
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       BlockDev& b = c->blocks[n].d;
-      const MarchPlan mp = march_plan(b);
+      const MarchPlan mp = march_plan(c, b);
       hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, c->stream,
                          c->partials + off, mp.nparts, c->norm_out + n);
       off += mp.nparts;
@@ -475,6 +487,12 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     c->use_tile = !strcmp(kn, "tile");
   }
   c->allow_fuse = !(getenv("AGX_NO_FUSE") && atoi(getenv("AGX_NO_FUSE")) != 0);
+  {
+    int ncu = 0;
+    HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+    if (ncu > 0) c->num_cu = ncu;
+    if (const char* w = getenv("AGX_WORKGROUPS")) c->num_cu = std::max(1, atoi(w));
+  }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
   HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
   HIPCHK(hipHostMalloc((void**)&c->err_host, sizeof(int)));
@@ -623,7 +641,7 @@ int agx_setup_finalize(agx_ctx* c) {
   for (auto& blk : c->blocks) {
     const dim3 g = cell_grid(blk.d, CELL_BLOCK);
     max_parts = std::max(max_parts, (long)g.x * g.y * g.z);
-    march_parts += march_plan(blk.d).nparts;
+    march_parts += march_plan(c, blk.d).nparts;
   }
   max_parts = std::max(max_parts, march_parts);
   for (auto& k : c->conns) {
@@ -733,7 +751,7 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
     Timer t(c, G_RESID);
     long off = 0;
     for (auto& blk : c->blocks) {
-      const MarchPlan mp = march_plan(blk.d);
+      const MarchPlan mp = march_plan(c, blk.d);
       MarchArgs ma;
       memset(&ma, 0, sizeof ma);
       ma.kchunk = mp.kchunk;

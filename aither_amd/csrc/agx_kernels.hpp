@@ -463,6 +463,13 @@ k_residual_march(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
 //     from global memory one step ahead; all i/j stencil reads are LDS reads;
 //   * one workgroup barrier per k-step publishes both the j-fluxes and the
 //     next plane.
+// diagnostic ablation switches (MarchArgs::ablate) exist only in builds made
+// with -DAGX_ABLATION; the production build compiles them away
+#ifdef AGX_ABLATION
+#define AGX_AB(bit) ((ma.ablate & (bit)) != 0)
+#else
+#define AGX_AB(bit) (false)
+#endif
 template <int RECON, int LIM, class Get, class GetW>
 __device__ __forceinline__ void recon_generic(Get get, GetW getw, double kappa,
                                               double* l, double* r) {
@@ -503,7 +510,7 @@ __device__ __forceinline__ void recon_generic(Get get, GetW getw, double kappa,
 }
 
 template <int RECON, int LIM, int FLUX, bool FUSE, int TJ>
-__global__ void __launch_bounds__(64 * (TJ + 2))
+__global__ void __launch_bounds__(64 * (TJ + 2), 2)
 k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
   constexpr int H = RECON == AGX_RECON_CONSTANT ? 1
                     : (RECON == AGX_RECON_MUSCL ? 2 : 3);
@@ -522,10 +529,6 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
   __shared__ double sFk[PARK ? TJ : 1][AGX_NEQ][64];
   __shared__ double sAk[PARK ? TJ : 1][4][64];
   const int lane = threadIdx.x, wv = threadIdx.y;
-  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * TJ;
-  const int k0 = blockIdx.z * ma.kchunk;
-  const int k1 = min(k0 + ma.kchunk, b.nk);
-  const int itop = min(i0 + 64, b.ni), jtop = min(j0 + TJ, b.nj);
   const long s_k = b.sxy;
   if (FUSE && wv < TJ) {
 #pragma unroll
@@ -533,6 +536,25 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
     sNorm[AGX_NEQ][wv][lane] = -1.0e300;
     sLin[wv][lane] = 0x7fffffffffffffffLL;
   }
+  // Persistent workgroups (one per CU): the (column tile, k) steps of the block
+  // are one linear sequence cut into gridDim.x equal ranges, so every CU
+  // finishes together whatever the block shape; a range that crosses into the
+  // next column re-primes its window there.  Workgroup n runs on XCD n % 8:
+  // ranges are dealt so that each XCD's L2 sees neighbouring columns.
+  const int gx = (b.ni + 63) / 64, gy = (b.nj + TJ - 1) / TJ;
+  const long S = (long)gx * gy * b.nk;
+  const int P = gridDim.x;
+  const int rr = P % 8 == 0 ? (int)(blockIdx.x % 8) * (P / 8) + (int)(blockIdx.x / 8)
+                            : (int)blockIdx.x;
+  long s_pos = S * rr / P;
+  const long s_end = S * (rr + 1) / P;
+  while (s_pos < s_end) {
+  const int col = (int)(s_pos / b.nk);
+  const int k0 = (int)(s_pos - (long)col * b.nk);
+  const int k1 = (int)min((long)b.nk, k0 + (s_end - s_pos));
+  s_pos += k1 - k0;
+  const int i0 = (col % gx) * 64, j0 = (col / gx) * TJ;
+  const int itop = min(i0 + 64, b.ni), jtop = min(j0 + TJ, b.nj);
   if (wv < TJ) {
     // ======================= cell waves =====================================
     const int i = i0 + lane, j = j0 + wv;
@@ -591,7 +613,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
       double ak_up[4];
       b.area(2, q + s_k, ak_up);
       double nxt[AGX_NEQ], nwk, nwi, nwj;
-      if (ma.ablate & 128) {
+      if AGX_AB(128) {
 #pragma unroll
         for (int e = 0; e < AGX_NEQ; ++e) nxt[e] = W[2 * H - 1][e];
         nwk = wk[0]; nwi = wk[0]; nwj = wk[0];
@@ -615,14 +637,14 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
       // ---- k face (upper): stencil from the register window ----
       if (cell) {
         double l[AGX_NEQ], r[AGX_NEQ], f[AGX_NEQ];
-        if (ma.ablate & 2) {
+        if AGX_AB(2) {
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) { l[e] = W[H - 1][e]; r[e] = W[H][e]; }
         } else {
           recon_generic<RECON, LIM>([&](int e, int m) { return W[m + H][e]; },
                                     [&](int m) { return wk[m + H]; }, sp.kappa, l, r);
         }
-        if (ma.ablate & 1) {
+        if AGX_AB(1) {
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) f[e] = l[e] + r[e] * ak_up[0];
         } else {
@@ -650,7 +672,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
             ak_reg[e] = ak_up[e];
           }
         }
-        sr_k = (ma.ablate & 16) ? 1.0 : specrad(ak_lo, ak_up);
+        sr_k = AGX_AB(16) ? 1.0 : specrad(ak_lo, ak_up);
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- i face (lower): stencil from the LDS plane; the upper face comes
@@ -662,7 +684,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
           b.area(0, q, ai_lo);
           b.area(0, q + 1, ai_up);
           const double* base = tc + to;
-          if (ma.ablate & 2) {
+          if AGX_AB(2) {
 #pragma unroll
             for (int e = 0; e < AGX_NEQ; ++e) { l[e] = base[e * PLANE - 1]; r[e] = base[e * PLANE]; }
           } else {
@@ -670,7 +692,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
                 [&](int e, int m) { return base[e * PLANE + m]; },
                 [&](int m) { return base[AGX_NEQ * PLANE + m]; }, sp.kappa, l, r);
           }
-          if (ma.ablate & 1) {
+          if AGX_AB(1) {
 #pragma unroll
             for (int e = 0; e < AGX_NEQ; ++e) fi[e] = l[e] + r[e] * ai_lo[0];
           } else {
@@ -678,7 +700,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
           }
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) fi[e] *= ai_lo[3];
-          sr_i = (ma.ablate & 16) ? 1.0 : specrad(ai_lo, ai_up);
+          sr_i = AGX_AB(16) ? 1.0 : specrad(ai_lo, ai_up);
         }
         const bool edge = i == itop - 1;
 #pragma unroll
@@ -694,7 +716,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         b.area(1, q, aj_lo);
         b.area(1, q + b.sx, aj_up);
         const double* base = tc + to;
-        if (ma.ablate & 2) {
+        if AGX_AB(2) {
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) { l[e] = base[e * PLANE - TW]; r[e] = base[e * PLANE]; }
         } else {
@@ -702,7 +724,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
               [&](int e, int m) { return base[e * PLANE + m * TW]; },
               [&](int m) { return base[(AGX_NEQ + 1) * PLANE + m * TW]; }, sp.kappa, l, r);
         }
-        if (ma.ablate & 1) {
+        if AGX_AB(1) {
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) f[e] = l[e] + r[e] * aj_lo[0];
         } else {
@@ -714,12 +736,12 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
           sFj[cur][wv][e][lane] = f[e];
           res[e] -= f[e];
         }
-        sr_j = (ma.ablate & 16) ? 1.0 : specrad(aj_lo, aj_up);
+        sr_j = AGX_AB(16) ? 1.0 : specrad(aj_lo, aj_up);
       }
       __builtin_amdgcn_sched_barrier(0);
       // publish the own entry of the next plane; the loads of the update fly
       // across the barrier
-      if (!(ma.ablate & 64)) {
+      if (!AGX_AB(64)) {
 #pragma unroll
         for (int e = 0; e < AGX_NEQ; ++e) tn[e * PLANE + to] = W[H][e];
         tn[AGX_NEQ * PLANE + to] = nwi;
@@ -741,7 +763,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         const double sr = (sr_i + sr_j) + sr_k;
         const double dt = sp.dt_fixed > 0.0 ? sp.dt_fixed
                                             : cfl * (vol * fast_rcp(fmax(sr, 0.0)));
-        const bool st_ok = !(ma.ablate & 4) || res[0] == 12345.678;
+        const bool st_ok = !AGX_AB(4) || res[0] == 12345.678;
         if (st_ok) {
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) b.pl(PL_RESID + e)[q] = res[e];
@@ -761,7 +783,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
           }
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) u[e] -= fac * res[e];
-          if (ma.ablate & 8) {
+          if AGX_AB(8) {
 #pragma unroll
             for (int e = 0; e < AGX_NEQ; ++e) ns[e] = u[e];
           } else {
@@ -845,7 +867,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
       const double* tc = &tile[cur][0][0][0];
       double* tn = &tile[cur ^ 1][0][0][0];
       double af[4] = {0, 0, 0, 1};
-      if (ma.ablate & 32) { __syncthreads(); continue; }
+      if AGX_AB(32) { __syncthreads(); continue; }
       if (do_f) b.area(top ? 1 : 0, qf + (long)k * s_k, af);
       // prefetch the halo ring of plane k+1
       double hv[NV][H], hcv[NV];
@@ -883,6 +905,8 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
       }
       __syncthreads();
     }
+  }
+  __syncthreads();   // segment boundary: the LDS buffers are reused
   }
   if (FUSE) {
     __syncthreads();
