@@ -240,17 +240,24 @@ def main():
         t_swp, n_swp = group(3)
         launches_per_step = n_res / max(args.steps, 1)
         if args.workload == "rk4":
-            # dominant kernel: k_inv_residual (one launch per stage per block)
-            achieved = BYTES_RESID_KERNEL * cells_rank / (t_res * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel="k_inv_residual<MUSCL,vanAlbada,Roe>",
+            fused = (os.environ.get("AGX_KERNEL", "tile") != "gather"
+                     and os.environ.get("AGX_NO_FUSE", "0") in ("", "0"))
+            # dominant kernel: one launch per RK stage per block.  Fused form
+            # (default): k_residual_tile does the whole stage (residual, dt,
+            # update, norms) = 296 B/cell; unfused: residual kernel 216 B/cell
+            # followed by k_update.
+            bpc = BYTES_STAGE if fused else BYTES_RESID_KERNEL
+            achieved = bpc * cells_rank / (t_res * 1e-3) / 1e9
+            stage_ms = t_res * launches_per_step + t_upd
+            roof = dict(bound="hbm",
+                        kernel=("k_residual_tile<MUSCL,vanAlbada,Roe,fused>" if fused
+                                else "residual kernel (unfused)"),
                         achieved=achieved, peak=HBM_PEAK / 1e9, unit="GB/s",
                         frac=achieved * 1e9 / HBM_PEAK, traffic=None,
-                        bytes_per_cell=BYTES_RESID_KERNEL,
-                        avg_launch_ms=t_res,
-                        stage=dict(bytes_per_cell=BYTES_STAGE,
-                                   device_ms=t_res * launches_per_step + t_upd,
+                        bytes_per_cell=bpc, avg_launch_ms=t_res,
+                        stage=dict(bytes_per_cell=BYTES_STAGE, device_ms=stage_ms,
                                    frac=BYTES_STAGE * cells_rank /
-                                   ((t_res * launches_per_step + t_upd) * 1e-3) / HBM_PEAK))
+                                   (stage_ms * 1e-3) / HBM_PEAK))
         else:
             dev_ms = (t_res * n_res + t_upd * n_upd + t_bc * n_bc +
                       t_swp * n_swp) / max(args.steps, 1)
@@ -263,7 +270,13 @@ def main():
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             with open(tp) as fh:
-                roof["traffic"] = json.load(fh).get(args.workload)
+                tr = json.load(fh).get(args.workload)
+            if tr and tr.get("cells") == cells_rank:
+                # HBM bytes per launch of the dominant kernel from separate
+                # rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
+                # correction, calibrated for 8-B lanes; WRITE_SIZE as read)
+                roof["traffic"] = tr["bytes_per_launch"]
+                roof["traffic_detail"] = tr
         out = {
             "metric": "Mcell-updates/sec per iteration (residual + update), "
                       f"{n}^3 block",
