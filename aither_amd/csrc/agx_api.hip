@@ -83,6 +83,7 @@ struct agx_ctx {
   int num_cu = 256;          // persistent workgroups of the tile kernel
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
+  bool consn_pending = false;   // AssignSolToTimeN deferred into the next fused stage-0 launch
   long fused_parts = 0;
   // timing: hipEvent pairs recorded on the library's stream around each
   // kernel group, resolved lazily in agx_timing_get (no sync while running)
@@ -331,11 +332,14 @@ void launch_inv_kernel(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
   }
   const dim3 tb(64, g_march_tj + 2);
   if (c->use_tile) {
-    if (fuse)
-      hipLaunchKernelGGL((k_residual_tile<RECON, LIM, FLUX, true, 6>), mp.grid, tb, 0,
+    if (fuse && ma.store_consn)
+      hipLaunchKernelGGL((k_residual_tile<RECON, LIM, FLUX, 2, 6>), mp.grid, tb, 0,
+                         c->stream, sd, c->gas, c->sp, cfl, ma);
+    else if (fuse)
+      hipLaunchKernelGGL((k_residual_tile<RECON, LIM, FLUX, 1, 6>), mp.grid, tb, 0,
                          c->stream, sd, c->gas, c->sp, cfl, ma);
     else
-      hipLaunchKernelGGL((k_residual_tile<RECON, LIM, FLUX, false, 6>), mp.grid, tb, 0,
+      hipLaunchKernelGGL((k_residual_tile<RECON, LIM, FLUX, 0, 6>), mp.grid, tb, 0,
                          c->stream, sd, c->gas, c->sp, cfl, ma);
   } else {
     if (fuse)
@@ -377,10 +381,23 @@ bool can_fuse(const agx_ctx* c) {
   return c->allow_fuse && !c->use_gather && !c->sp.implicit && !c->sp.viscous;
 }
 
+// consVarsN = cons(state) that agx_store_time_n deferred (see there)
+int flush_consn(agx_ctx* c) {
+  if (!c->consn_pending) return 0;
+  c->consn_pending = false;
+  for (auto& blk : c->blocks)
+    hipLaunchKernelGGL(k_store_time_n, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
+                       0, c->stream, blk.d, c->gas, 0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+
 int bc_pass(agx_ctx* c, bool faces, int viscous) {
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
     if (faces) {
+      long nmax = 0;
       for (int sn = 0; sn < b.nsurf; ++sn) {
         const agx_bc_surface& s = blk.surf_host[sn];
         if (s.bc_type == AGX_BC_INTERBLOCK || s.bc_type == AGX_BC_PERIODIC) continue;
@@ -388,11 +405,11 @@ int bc_pass(agx_ctx* c, bool faces, int viscous) {
         const int st = surface_type(s);
         const int d3 = (st - 1) / 2, d1 = (d3 + 1) % 3, d2 = (d3 + 2) % 3;
         const int lo[3] = {s.imin, s.jmin, s.kmin}, hi[3] = {s.imax, s.jmax, s.kmax};
-        const long n = (long)(hi[d1] - lo[d1]) * (hi[d2] - lo[d2]) * b.ng;
-        if (n <= 0) continue;
-        hipLaunchKernelGGL(k_bc_faces, dim3((n + 255) / 256), dim3(256), 0,
-                           c->stream, b, c->gas, sn, viscous, c->err_dev);
+        nmax = std::max(nmax, (long)(hi[d1] - lo[d1]) * (hi[d2] - lo[d2]) * b.ng);
       }
+      if (nmax > 0)
+        hipLaunchKernelGGL(k_bc_faces, dim3((nmax + 255) / 256, b.nsurf), dim3(256), 0,
+                           c->stream, b, c->gas, viscous, c->err_dev);
     } else {
       const long n = 4L * (b.ni + b.nj + b.nk);
       hipLaunchKernelGGL(k_bc_edges, dim3((n + 127) / 128), dim3(128), 0,
@@ -689,6 +706,7 @@ int agx_setup_finalize(agx_ctx* c) {
 }
 
 int agx_state_upload(agx_ctx* c, int id, const double* state) {
+  if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
   const BlockDev& d = b.d;
@@ -713,6 +731,7 @@ static int field_info(Block& b, int field, double* const** p, int* ncomp, int* g
 }
 
 int agx_field_download(agx_ctx* c, int id, int field, double* out) {
+  if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
   double* const* p; int nc, gh;
@@ -723,6 +742,7 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
   return download_aos(c, b, out, p, nc, b.d.ni + 2 * g, b.d.nj + 2 * g, b.d.nk + 2 * g, g);
 }
 int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
+  if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
   double* const* p; int nc, gh;
@@ -732,6 +752,13 @@ int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
 }
 
 int agx_store_time_n(agx_ctx* c, int also_nm1) {
+  if (flush_consn(c)) return 1;
+  // Explicit fused path: the stage-0 launch of k_residual_tile forms
+  // cons(state) anyway and writes it to consVarsN itself (5 stores instead of a
+  // separate 5-load/5-store pass); anything else that touches consVarsN or the
+  // state first calls flush_consn().
+  static const bool lazy = !(getenv("AGX_NO_LAZY_CONSN") && atoi(getenv("AGX_NO_LAZY_CONSN")));
+  if (lazy && !also_nm1 && can_fuse(c) && c->use_tile) { c->consn_pending = true; return 0; }
   for (auto& blk : c->blocks)
     hipLaunchKernelGGL(k_store_time_n, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
                        0, c->stream, blk.d, c->gas, also_nm1);
@@ -747,6 +774,9 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
   if (c->cfg.dt_nondim <= 0.0 && cfl <= 0.0)
     return fail("Neither dt or cfl was specified!");   // procBlock.cpp:813-816
   const bool fuse = can_fuse(c);
+  const int store_consn = fuse && c->use_tile && c->consn_pending && mm == 0;
+  if (store_consn) c->consn_pending = false;
+  else if (flush_consn(c)) return 1;
   {
     Timer t(c, G_RESID);
     long off = 0;
@@ -756,6 +786,7 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
       memset(&ma, 0, sizeof ma);
       ma.kchunk = mp.kchunk;
       ma.mode = c->cfg.time_integration == AGX_TIME_RK4 ? 1 : 0;
+      ma.store_consn = store_consn;
       const double rk_alpha[4] = {0.25, 1.0 / 3.0, 0.5, 1.0};   // procBlock.cpp:938
       ma.alpha = rk_alpha[mm & 3];
       ma.partials = c->partials + off;

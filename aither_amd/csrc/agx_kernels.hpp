@@ -211,6 +211,7 @@ struct MarchArgs {
   int kchunk;              // k planes per workgroup
   int mode;                // FUSE: 0 explicit Euler, 1 RK stage
   double alpha;            // RK stage coefficient
+  int store_consn;         // fused stage 0: also write cons(state) to consVarsN
   int ablate;              // diagnostic (AGX_ABLATE): 1 no flux math, 2 no
                            // reconstruction, 4 no stores, 8 no cons->prim,
                            // 16 no spectral radius, 32 idle halo waves,
@@ -509,7 +510,8 @@ __device__ __forceinline__ void recon_generic(Get get, GetW getw, double kappa,
   }
 }
 
-template <int RECON, int LIM, int FLUX, bool FUSE, int TJ>
+// FUSE: 0 residual only, 1 + explicit stage update, 2 + AssignSolToTimeN (stage 0)
+template <int RECON, int LIM, int FLUX, int FUSE, int TJ>
 __global__ void __launch_bounds__(64 * (TJ + 2), 2)
 k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
   constexpr int H = RECON == AGX_RECON_CONSTANT ? 1
@@ -751,7 +753,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
       double cn[AGX_NEQ];
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e)
-        cn[e] = (FUSE && ma.mode != 0) ? b.pl(PL_CONSN + e)[q] : 0.0;
+        cn[e] = (FUSE == 1 && ma.mode != 0) ? b.pl(PL_CONSN + e)[q] : 0.0;
       __syncthreads();
       if (cell) {
 #pragma unroll
@@ -774,13 +776,17 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         if (FUSE) {
           double u[AGX_NEQ], ns[AGX_NEQ];
           double fac = dt * fast_rcp(vol);
-          if (ma.mode == 0) {
-            prim_to_cons(g, sc, u);
+          if (ma.mode == 0 || FUSE == 2) {
+            prim_to_cons(g, sc, u);            // U_n of this step
+            if (FUSE == 2 && st_ok) {          // AssignSolToTimeN procBlock.cpp:1037
+#pragma unroll
+              for (int e = 0; e < AGX_NEQ; ++e) b.pl(PL_CONSN + e)[q] = u[e];
+            }
           } else {
 #pragma unroll
             for (int e = 0; e < AGX_NEQ; ++e) u[e] = cn[e];
-            fac *= ma.alpha;
           }
+          if (ma.mode != 0) fac *= ma.alpha;
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) u[e] -= fac * res[e];
           if AGX_AB(8) {
@@ -1122,11 +1128,13 @@ __host__ __device__ inline int surface_type(const agx_bc_surface& s) {
   return s.kmax == 0 ? 5 : 6;
 }
 
-// Face ghost cells of ONE surface: procBlock::AssignInviscidGhostCells
-// procBlock.cpp:2449-2532 (viscous = 0) / AssignViscousGhostCells :2760-2838
-// (viscous = 1, viscousWall surfaces only).  All layers and surfaces are
-// independent (they read physical cells only), so they run concurrently.
-__global__ void k_bc_faces(BlockDev b, GasDev g, int sn, int viscous, int* err) {
+// Face ghost cells: procBlock::AssignInviscidGhostCells procBlock.cpp:2449-2532
+// (viscous = 0) / AssignViscousGhostCells :2760-2838 (viscous = 1, viscousWall
+// surfaces only).  All layers and surfaces are independent (they read physical
+// cells only), so one launch covers every surface of the block: blockIdx.y is
+// the surface, blockIdx.x * blockDim.x + threadIdx.x the ghost cell on it.
+__global__ void k_bc_faces(BlockDev b, GasDev g, int viscous, int* err) {
+  const int sn = blockIdx.y;
   const agx_bc_surface sf = b.surf[sn];
   const int st = surface_type(sf);
   const int d3 = (st - 1) / 2, d1 = (d3 + 1) % 3, d2 = (d3 + 2) % 3;
