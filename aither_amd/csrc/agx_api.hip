@@ -39,6 +39,7 @@ struct Block {
   BlockDev d;
   int global_pos = 0;
   double* slab = nullptr;
+  double* rec = nullptr;      // LU-SGS sweep records
   bool state_is_a = true;
   agx_bc_surface* surf_dev = nullptr;
   std::vector<agx_bc_surface> surf_host;
@@ -81,8 +82,11 @@ struct agx_ctx {
   bool use_gather = false;   // AGX_KERNEL=gather: one-thread-per-cell gather kernel
   bool use_tile = true;      // AGX_KERNEL=tile (default) | march
   int num_cu = 256;          // persistent workgroups of the tile kernel
+  bool lusgs_plane = false;  // AGX_LUSGS=plane: one launch per fine hyperplane
+  int lusgs_lbi = 16;        // brick length along i (AGX_LBI=8|16)
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
+  bool x_in_records = false;    // LU-SGS: newest x is in rec_dyn, SoA planes stale
   bool consn_pending = false;   // AssignSolToTimeN deferred into the next fused stage-0 launch
   long fused_parts = 0;
   // timing: hipEvent pairs recorded on the library's stream around each
@@ -145,6 +149,7 @@ int derive_gas(const agx_config& cfg, GasDev& g) {
   g.cv = a.gas_constant * a.n;
   g.gamma = g.cp / g.cv;
   g.prandtl = (4.0 * g.gamma) / (9.0 * g.gamma - 5.0);
+  g.inv_prandtl = 1.0 / g.prandtl;
   g.visc_c1 = a.visc_c1; g.visc_s = a.visc_s;
   g.cond_c1 = a.cond_c1; g.cond_s = a.cond_s;
   g.t_ref = a.t_ref;
@@ -381,6 +386,57 @@ bool can_fuse(const agx_ctx* c) {
   return c->allow_fuse && !c->use_gather && !c->sp.implicit && !c->sp.viscous;
 }
 
+// One LU-SGS half sweep over a block: coarse hyperplanes of LBI x 8 x 8 bricks,
+// one launch each (k_lusgs_brick); AGX_LUSGS=plane selects the one-launch-per-
+// fine-hyperplane form kept for comparison.
+template <bool FWD, int LBI>
+void lusgs_brick_launches(agx_ctx* c, const BlockDev& b, int full) {
+  const int nbi = (b.ni + LBI - 1) / LBI, nbj = (b.nj + 7) / 8, nbk = (b.nk + 7) / 8;
+  const dim3 tb(64, 4), grid((nbj * nbk + 3) / 4);
+  const int ncp = nbi + nbj + nbk - 2;
+  for (int t = 0; t < ncp; ++t) {
+    const int p = FWD ? t : ncp - 1 - t;
+    hipLaunchKernelGGL((k_lusgs_brick<FWD, LBI>), grid, tb, 0, c->stream, b, c->gas,
+                       c->sp, p, full, nbi, nbj, nbk);
+  }
+}
+// x of the brick sweeps lives in the records until somebody needs the SoA planes
+int flush_x(agx_ctx* c) {
+  if (!c->x_in_records) return 0;
+  c->x_in_records = false;
+  for (auto& blk : c->blocks)
+    hipLaunchKernelGGL(k_lusgs_unpack, dim3((blk.d.nplane + 255) / 256), dim3(256), 0,
+                       c->stream, blk.d);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+void lusgs_sweep(agx_ctx* c, const BlockDev& b, bool forward, int full) {
+  if (c->lusgs_plane) {
+    const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
+    const int nplanes = b.ni + b.nj + b.nk - 2;
+    for (int t = 0; t < nplanes; ++t) {
+      const int p = forward ? t : nplanes - 1 - t;
+      if (forward)
+        hipLaunchKernelGGL((k_lusgs_plane<true>), grid, tb, 0, c->stream, b, c->gas,
+                           c->sp, p, full);
+      else
+        hipLaunchKernelGGL((k_lusgs_plane<false>), grid, tb, 0, c->stream, b, c->gas,
+                           c->sp, p, full);
+    }
+    return;
+  }
+  if (!c->x_in_records)
+    hipLaunchKernelGGL(k_lusgs_pack, dim3((b.nplane + 255) / 256), dim3(256), 0, c->stream,
+                       b, c->gas, c->sp);
+  if (c->lusgs_lbi == 8) {
+    if (forward) lusgs_brick_launches<true, 8>(c, b, full);
+    else lusgs_brick_launches<false, 8>(c, b, full);
+  } else {
+    if (forward) lusgs_brick_launches<true, 16>(c, b, full);
+    else lusgs_brick_launches<false, 16>(c, b, full);
+  }
+}
+
 // consVarsN = cons(state) that agx_store_time_n deferred (see there)
 int flush_consn(agx_ctx* c) {
   if (!c->consn_pending) return 0;
@@ -509,6 +565,8 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
     if (ncu > 0) c->num_cu = ncu;
     if (const char* w = getenv("AGX_WORKGROUPS")) c->num_cu = std::max(1, atoi(w));
+    if (const char* w = getenv("AGX_LUSGS")) c->lusgs_plane = !strcmp(w, "plane");
+    if (const char* w = getenv("AGX_LBI")) c->lusgs_lbi = atoi(w) == 8 ? 8 : 16;
   }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
   HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
@@ -524,6 +582,7 @@ void agx_ctx_destroy(agx_ctx* c) {
   hipStreamSynchronize(c->stream);
   for (auto& b : c->blocks) {
     if (b.slab) hipFree(b.slab);
+    if (b.rec) hipFree(b.rec);
     if (b.surf_dev) hipFree(b.surf_dev);
   }
   for (auto& k : c->conns) {
@@ -608,6 +667,13 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
     for (int cc = 0; cc < 4; ++cc) d.fa[q][cc] = pl(PL_FA + 4 * q + cc);
   }
   b.state_is_a = true;
+  if (c->sp.implicit && c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
+    // two 128-byte records per cell for the LU-SGS sweeps (k_lusgs_brick)
+    HIPCHK(hipMalloc((void**)&b.rec, sizeof(double) * d.nplane * LREC * 2));
+    d.rec_dyn = b.rec;
+    d.rec_geo = b.rec + d.nplane * LREC;
+    HIPCHK(hipMemsetAsync(b.rec, 0, sizeof(double) * d.nplane * LREC * 2, c->stream));
+  }
   const int ci = d.ni + 2 * d.ng, cj = d.nj + 2 * d.ng, ck = d.nk + 2 * d.ng;
   if (upload_aos(c, b, g->farea_i, d.fa[0], 4, ci + 1, cj, ck, d.ng)) return 1;
   if (upload_aos(c, b, g->farea_j, d.fa[1], 4, ci, cj + 1, ck, d.ng)) return 1;
@@ -620,6 +686,9 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
     double* wp[1] = {d.wid[q]};
     if (upload_aos(c, b, wsrc[q], wp, 1, ci, cj, ck, d.ng)) return 1;
   }
+  if (d.rec_geo)
+    hipLaunchKernelGGL(k_lusgs_geo, dim3((d.nplane + 255) / 256), dim3(256), 0, c->stream, d);
+  HIPCHK(hipGetLastError());
   *block_id = (int)c->blocks.size() - 1;
   return 0;
 }
@@ -731,6 +800,7 @@ static int field_info(Block& b, int field, double* const** p, int* ncomp, int* g
 }
 
 int agx_field_download(agx_ctx* c, int id, int field, double* out) {
+  if (flush_x(c)) return 1;
   if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
@@ -742,6 +812,7 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
   return download_aos(c, b, out, p, nc, b.d.ni + 2 * g, b.d.nj + 2 * g, b.d.nk + 2 * g, g);
 }
 int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
+  if (flush_x(c)) return 1;
   if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
@@ -818,6 +889,7 @@ int agx_phase_explicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
 }
 
 int agx_phase_implicit_begin(agx_ctx* c) {
+  if (flush_x(c)) return 1;
   Timer t(c, G_SWEEP);
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
@@ -834,14 +906,12 @@ int agx_phase_implicit_begin(agx_ctx* c) {
 int agx_phase_relax_forward(agx_ctx* c, int sweep) {
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
+  bool swept = false;
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
     if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
-      const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
-      const int nplanes = b.ni + b.nj + b.nk - 2;
-      for (int p = 0; p < nplanes; ++p)
-        hipLaunchKernelGGL((k_lusgs_plane<true>), grid, tb, 0, c->stream, b,
-                           c->gas, c->sp, p, full);
+      lusgs_sweep(c, b, true, full);
+      swept = true;
     } else {
       hipLaunchKernelGGL(k_copy5, dim3((b.nplane + 255) / 256), dim3(256), 0,
                          c->stream, planes(b.xold), planes(b.x), b.nplane);
@@ -849,6 +919,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
                          c->stream, b, c->gas, c->sp);
     }
   }
+  if (swept && !c->lusgs_plane) c->x_in_records = true;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -859,17 +930,15 @@ int agx_phase_relax_backward(agx_ctx* c, int sweep) {
   const int full = sweep > 0 || c->sp.requires_init;
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
-    const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
-    const int nplanes = b.ni + b.nj + b.nk - 2;
-    for (int p = nplanes - 1; p >= 0; --p)
-      hipLaunchKernelGGL((k_lusgs_plane<false>), grid, tb, 0, c->stream, b,
-                         c->gas, c->sp, p, full);
+    lusgs_sweep(c, b, false, full);
   }
+  if (!c->lusgs_plane) c->x_in_records = true;
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
+  if (flush_x(c)) return 1;
   double sumsq = 0.0;
   long size = 0;
   {
@@ -897,11 +966,14 @@ int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
 }
 
 int agx_phase_implicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
+  if (flush_x(c)) return 1;
   return update_pass(c, 2, mm, l2, linf);
 }
 
 // ---- halo -----------------------------------------------------------------
 int agx_halo_swap_local(agx_ctx* c, int what) {
+  if (c->conns.empty()) return 0;
+  if (flush_x(c)) return 1;
   Timer t(c, G_BC);
   for (auto& k : c->conns) {
     const agx_connection& cc = k.c;
@@ -940,6 +1012,7 @@ int64_t agx_halo_count(agx_ctx* c, int id, int what) {
   return (int64_t)AGX_NEQ * std::max(k.n_send, k.side[s].n);
 }
 int agx_halo_pack(agx_ctx* c, int id, int what, double* dev_buf) {
+  if (flush_x(c)) return 1;
   if (id < 0 || id >= (int)c->conns.size()) return fail("bad connection id");
   Conn& k = c->conns[id];
   const int s = my_side(c, k);
@@ -952,6 +1025,7 @@ int agx_halo_pack(agx_ctx* c, int id, int what, double* dev_buf) {
   return 0;
 }
 int agx_halo_unpack(agx_ctx* c, int id, int what, const double* dev_buf) {
+  if (flush_x(c)) return 1;
   if (id < 0 || id >= (int)c->conns.size()) return fail("bad connection id");
   Conn& k = c->conns[id];
   const int s = my_side(c, k);

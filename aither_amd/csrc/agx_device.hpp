@@ -28,6 +28,7 @@ struct GasDev {
   double k_nondim;  // sutherland::kNonDim_      transport.cpp:67
   double scaling;   // transport::NondimScaling  transport.hpp:43-46
   double inv_n;     // 1 / n
+  double inv_prandtl;
 };
 
 struct Prim {  // primitive: rho, u, v, w, p  (varArray.hpp:40-51)
@@ -57,7 +58,7 @@ __device__ __forceinline__ double fast_sqrt(double x) { return x * fast_rsqrt(x)
 
 // idealGas::Temperature eos.cpp:100-109
 __device__ __forceinline__ double temperature(const GasDev& g, const double* s) {
-  return s[4] / (s[0] * g.R);
+  return s[4] * fast_rcp(s[0] * g.R);
 }
 // SpeedOfSound arrayView.hpp:383-391
 __device__ __forceinline__ double sound_speed(const GasDev& g, const double* s) {
@@ -109,12 +110,12 @@ __device__ __forceinline__ void update_prim_with_cons(const GasDev& g,
 // sutherland::SpeciesViscosity transport.cpp:114-122
 __device__ __forceinline__ double viscosity(const GasDev& g, double t) {
   const double temp = t * g.t_ref;
-  return (g.visc_c1 * temp * sqrt(temp)) / (temp + g.visc_s) / g.mu_ref;
+  return (g.visc_c1 * temp * fast_sqrt(temp)) * fast_rcp((temp + g.visc_s) * g.mu_ref);
 }
 // sutherland::SpeciesConductivity transport.cpp:124-132
 __device__ __forceinline__ double conductivity(const GasDev& g, double t) {
   const double temp = t * g.t_ref;
-  return (g.cond_c1 * temp * sqrt(temp)) / (temp + g.cond_s) / g.k_nondim;
+  return (g.cond_c1 * temp * fast_sqrt(temp)) * fast_rcp((temp + g.cond_s) * g.k_nondim);
 }
 
 // ---- limiters src/limiter.cpp:24-54 ---------------------------------------
@@ -192,13 +193,16 @@ __device__ __forceinline__ void lagrange_coeff(const double* w, int rr, int ii,
           denom *= stencil_width(w, ii - rr + ll, ii - rr + mm);
         }
       }
-      c += numer / denom;
+      c += fast_div(numer, denom);
     }
     coeffs[jj] = c * w[ii - rr + jj];
   }
 }
 struct WenoCoeffs {  // everything that depends on cell widths only
   double c0[3], c1[3], c2[3], lw0, lw1, lw2;
+  // reciprocals of the width-only denominators of Derivative2nd / Beta0-2:
+  // ih[a] = 1 / (0.5 (cw[a] + cw[a+1])), iq[m] = 1 / (0.25 (cw[m+2] + cw[m]) + 0.5 cw[m+1])
+  double ih[4], iq[3];
 };
 __device__ __forceinline__ void weno_coeffs(const double* cw, WenoCoeffs& k) {
   double cf[5];
@@ -206,26 +210,33 @@ __device__ __forceinline__ void weno_coeffs(const double* cw, WenoCoeffs& k) {
   lagrange_coeff<2>(cw, 1, 2, k.c1);
   lagrange_coeff<2>(cw, 0, 2, k.c2);
   lagrange_coeff<4>(cw, 2, 2, cf);
-  k.lw0 = cf[0] / k.c0[0];
-  k.lw1 = cf[4] / k.c2[2];
+  k.lw0 = fast_div(cf[0], k.c0[0]);
+  k.lw1 = fast_div(cf[4], k.c2[2]);
   k.lw2 = 1.0 - k.lw0 - k.lw1;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) k.ih[a] = fast_rcp(0.5 * (cw[a] + cw[a + 1]));
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+    k.iq[m] = fast_rcp(0.25 * (cw[m + 2] + cw[m]) + 0.5 * cw[m + 1]);
 }
 // Derivative2nd utility.hpp:114-120, BetaIntegral / Beta0/1/2
 // reconstruction.hpp:158-240
 __device__ __forceinline__ double beta_int(double d1, double d2, double dx,
                                            double xl, double xh) {
   const double dx3 = dx * dx * dx;
+  const double third = 1.0 / 3.0;
   const double fh = (d1 * d1 * xh + d1 * d2 * xh * xh +
-                     d2 * d2 * (xh * xh * xh) / 3.0) * dx + d2 * d2 * xh * dx3;
+                     d2 * d2 * (xh * xh * xh) * third) * dx + d2 * d2 * xh * dx3;
   const double fl = (d1 * d1 * xl + d1 * d2 * xl * xl +
-                     d2 * d2 * (xl * xl * xl) / 3.0) * dx + d2 * d2 * xl * dx3;
+                     d2 * d2 * (xl * xl * xl) * third) * dx + d2 * d2 * xl * dx3;
   return fh - fl;
 }
-__device__ __forceinline__ double deriv2(double x0, double x1, double x2,
+// ih21 = 1 / (0.5 (x2 + x1)), ih10 = 1 / (0.5 (x1 + x0)), iq = 1 / (0.25 (x2 + x0) + 0.5 x1)
+__device__ __forceinline__ double deriv2(double ih10, double ih21, double iq,
                                          double y0, double y1, double y2) {
-  const double fwd = (y2 - y1) / (0.5 * (x2 + x1));
-  const double bck = (y1 - y0) / (0.5 * (x1 + x0));
-  return (fwd - bck) / (0.25 * (x2 + x0) + 0.5 * x1);
+  const double fwd = (y2 - y1) * ih21;
+  const double bck = (y1 - y0) * ih10;
+  return (fwd - bck) * iq;
 }
 template <bool WENOZ>
 __device__ __forceinline__ double weno(const WenoCoeffs& k, const double* cw,
@@ -236,35 +247,35 @@ __device__ __forceinline__ double weno(const WenoCoeffs& k, const double* cw,
   const double s2 = k.c2[0] * u1 + k.c2[1] * d1 + k.c2[2] * d2;
   double b0, b1, b2;
   {
-    const double dd = deriv2(cw[0], cw[1], cw[2], u3, u2, u1);
-    const double df = (u1 - u2) / (0.5 * (cw[2] + cw[1])) + 0.5 * cw[2] * dd;
+    const double dd = deriv2(k.ih[0], k.ih[1], k.iq[0], u3, u2, u1);
+    const double df = (u1 - u2) * k.ih[1] + 0.5 * cw[2] * dd;
     b0 = beta_int(df, dd, cw[2], -0.5 * cw[2], 0.5 * cw[2]);
   }
   {
-    const double dd = deriv2(cw[1], cw[2], cw[3], u2, u1, d1);
-    const double df = (d1 - u1) / (0.5 * (cw[3] + cw[2])) - 0.5 * cw[2] * dd;
+    const double dd = deriv2(k.ih[1], k.ih[2], k.iq[1], u2, u1, d1);
+    const double df = (d1 - u1) * k.ih[2] - 0.5 * cw[2] * dd;
     b1 = beta_int(df, dd, cw[2], -0.5 * cw[2], 0.5 * cw[2]);
   }
   {
-    const double dd = deriv2(cw[2], cw[3], cw[4], u1, d1, d2);
-    const double df = (d1 - u1) / (0.5 * (cw[3] + cw[2])) - 0.5 * cw[2] * dd;
+    const double dd = deriv2(k.ih[2], k.ih[3], k.iq[2], u1, d1, d2);
+    const double df = (d1 - u1) * k.ih[2] - 0.5 * cw[2] * dd;
     b2 = beta_int(df, dd, cw[2], -0.5 * cw[2], 0.5 * cw[2]);
   }
   double n0, n1, n2;
   if (WENOZ) {
     const double tau5 = fabs(b0 - b2);
-    const double q0 = tau5 / (1.0e-40 + b0), q1 = tau5 / (1.0e-40 + b1),
-                 q2 = tau5 / (1.0e-40 + b2);
+    const double q0 = fast_div(tau5, 1.0e-40 + b0), q1 = fast_div(tau5, 1.0e-40 + b1),
+                 q2 = fast_div(tau5, 1.0e-40 + b2);
     n0 = k.lw0 * (1.0 + q0 * q0);
     n1 = k.lw1 * (1.0 + q1 * q1);
     n2 = k.lw2 * (1.0 + q2 * q2);
   } else {
     const double e0 = 1.0e-6 + b0, e1 = 1.0e-6 + b1, e2 = 1.0e-6 + b2;
-    n0 = k.lw0 / (e0 * e0);
-    n1 = k.lw1 / (e1 * e1);
-    n2 = k.lw2 / (e2 * e2);
+    n0 = fast_div(k.lw0, e0 * e0);
+    n1 = fast_div(k.lw1, e1 * e1);
+    n2 = fast_div(k.lw2, e2 * e2);
   }
-  const double inv = 1.0 / (n0 + n1 + n2);
+  const double inv = fast_rcp(n0 + n1 + n2);
   return (n0 * s0 + n1 * s1 + n2 * s2) * inv;
 }
 
@@ -407,10 +418,11 @@ __device__ __forceinline__ double inv_cell_spec_rad(const GasDev& g,
 }
 // viscous term of ViscCell/FaceSpectralRadius spectralRadius.hpp:94-160
 __device__ __forceinline__ double visc_max_term(const GasDev& g, double rho) {
-  return fmax(4.0 / (3.0 * rho), g.gamma / rho);
+  const double ir = fast_rcp(rho);
+  return fmax((4.0 / 3.0) * ir, g.gamma * ir);
 }
 __device__ __forceinline__ double visc_term(const GasDev& g, double mu) {
-  return g.scaling * (mu / g.prandtl);
+  return g.scaling * (mu * g.inv_prandtl);
 }
 
 // RusanovScalarOffDiagonal fluxJacobian.cpp:122-162 with FaceSpectralRadius
@@ -425,7 +437,7 @@ __device__ __forceinline__ void off_diagonal(const GasDev& g, bool viscous,
   phys_flux(g, s, area, fo);
   phys_flux(g, su, area, fn);
   double sr = 0.5 * area[3] * (fabs(dot3(s + 1, area)) + sound_speed(g, s));
-  if (viscous) sr += area[3] / dist * visc_max_term(g, s[0]) * visc_term(g, mu);
+  if (viscous) sr += area[3] * fast_rcp(dist) * visc_max_term(g, s[0]) * visc_term(g, mu);
   const double sg = positive ? 1.0 : -1.0;
 #pragma unroll
   for (int e = 0; e < AGX_NEQ; ++e)

@@ -35,6 +35,8 @@ struct BlockDev {
   double* xold[AGX_NEQ];      // dplur copy              linearSolver.cpp:487
   double* a;                  // linearSolver::a_ (scalar flow part)
   double* ainv;               // linearSolver::aInv_
+  double* rec_dyn;            // LU-SGS sweep records, 16 doubles per cell (below)
+  double* rec_geo;
   const agx_bc_surface* surf; // boundaryConditions      boundaryConditions.hpp:231
   int nsurf, nsurf_i, nsurf_j, nsurf_k;
   __host__ __device__ long idx(int i, int j, int k) const {
@@ -1540,6 +1542,360 @@ __global__ void k_lusgs_plane(BlockDev b, GasDev g, SolverDev sp, int plane, int
     }
   }
   store5(b.x, q, acc);
+}
+
+// ---------------------------------------------------------------------------
+// LU-SGS as a two-level wavefront (production form of the sweeps).
+//
+// The block is cut into bricks of LBI x 8 x 8 cells.  Bricks on a coarse
+// hyperplane BI+BJ+BK = P are independent and form one launch; inside a brick
+// ONE WAVE walks the fine hyperplanes li+lj+lk = s.  Lane (lj, lk) owns the
+// i-line (., lj, lk) of the brick and meets its cells in order, so
+//   * the i-neighbour on the sweep side is the lane's own previous cell
+//     (registers),
+//   * the j / k neighbours are what lanes -+1 / -+8 finished in the previous
+//     step (wave shuffles),
+//   * only neighbours outside the brick are read from memory, and those were
+//     completed by earlier launches,
+// i.e. there is no memory round trip on the dependency chain.  Any topological
+// order of the dependency graph gives the same x as the reference's global
+// hyperplane order (HyperplaneReorder utility.cpp:377-398), so results are
+// unchanged.
+//
+// Cells that are in flight together always lie in different grid rows, so SoA
+// planes would cost one 128-byte line per 8-byte value.  For the sweeps the
+// per-cell data is therefore gathered into two 128-byte records per cell
+// (k_lusgs_pack / k_lusgs_geo), read whole by the owning lane:
+//   rec_dyn[q] = { x[5], 1/A, state[5], b[5] }      b = right-hand side
+//   rec_geo[q] = { centre[3], areaI[4], areaJ[4], areaK[4], mu }  lower faces
+// Follows lusgs::LUSGS_Forward linearSolver.cpp:341-383 / LUSGS_Backward
+// :385-428 with procBlock::ImplicitLower / ImplicitUpper procBlock.cpp:1056-1163.
+constexpr int LREC = 16;
+__device__ __forceinline__ void lusgs_ld(const double* p, int first, int count2,
+                                         double* out) {
+  // count2 aligned double2 loads starting at double index `first` (even)
+  const double2* v = reinterpret_cast<const double2*>(p + first);
+#pragma unroll
+  for (int m = 0; m < count2; ++m) {
+    const double2 t = v[m];
+    out[2 * m] = t.x;
+    out[2 * m + 1] = t.y;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_lusgs_geo(BlockDev b) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nplane) return;
+  double* r = b.rec_geo + q * LREC;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    r[d] = b.cen[d][q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[3 + 4 * d + c] = b.fa[d][c][q];
+  }
+  r[15] = 0.0;
+}
+
+// SoA -> records before a half sweep (all padded cells: ghost cells carry the
+// state and the exchanged x of the neighbouring block)
+__global__ void __launch_bounds__(256) k_lusgs_pack(BlockDev b, GasDev g, SolverDev sp) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nplane) return;
+  const int k = (int)(q / b.sxy) - b.ng;
+  const long rem = q % b.sxy;
+  const int j = (int)(rem / b.sx) - b.ng, i = (int)(rem % b.sx) - b.ioff;
+  const bool phys = i >= 0 && i < b.ni && j >= 0 && j < b.nj && k >= 0 && k < b.nk;
+  double r[LREC];
+  load5(b.x, q, r);
+  load5(b.state, q, r + 6);
+  r[5] = 0.0;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) r[11 + e] = 0.0;
+  if (phys) {
+    r[5] = b.ainv[q];
+    rhs_b(b, g, sp, q, r + 11);
+  }
+  double2* o = reinterpret_cast<double2*>(b.rec_dyn + q * LREC);
+#pragma unroll
+  for (int m = 0; m < LREC / 2; ++m) o[m] = make_double2(r[2 * m], r[2 * m + 1]);
+  // laminar viscosity of the cell (UpdateAuxillaryVariables procBlock.cpp:6171)
+  // rides in the spare slot of the geometry record
+  if (sp.viscous) b.rec_geo[q * LREC + 15] = r[6] > 0.0 ? viscosity(g, temperature(g, r + 6)) : 0.0;
+}
+// records -> SoA x after a half sweep
+__global__ void __launch_bounds__(256) k_lusgs_unpack(BlockDev b) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nplane) return;
+  double x[6];
+  lusgs_ld(b.rec_dyn + q * LREC, 0, 3, x);
+  store5(b.x, q, x);
+}
+
+struct LusgsNbr { double x[AGX_NEQ], s[AGX_NEQ], c[3], mu, a[4]; };   // a: backward only
+struct LusgsDone { double x[AGX_NEQ], s[AGX_NEQ], c[3], mu, area[3][4]; };
+
+template <bool FORWARD>
+__device__ __forceinline__ void lusgs_load_nbr(const BlockDev& b, bool viscous, long q,
+                                               int d, LusgsNbr& n) {
+  double t[12];
+  lusgs_ld(b.rec_dyn + q * LREC, 0, 6, t);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) { n.x[e] = t[e]; n.s[e] = t[6 + e]; }
+  const double* gr = b.rec_geo + q * LREC;
+  n.mu = 0.0;
+  if (viscous) { n.c[0] = gr[0]; n.c[1] = gr[1]; n.c[2] = gr[2]; n.mu = gr[15]; }
+  if (!FORWARD) {
+    // the face between the two cells is the neighbour's lower face
+#pragma unroll
+    for (int c = 0; c < 4; ++c) n.a[c] = gr[3 + 4 * d + c];
+  }
+}
+// one neighbour's contribution; `cen` is the own cell's centre, `lower` says on
+// which side the neighbour sits (face `area` is the one between the two cells)
+__device__ __forceinline__ void lusgs_nbr_term(const GasDev& g, const SolverDev& sp,
+                                               const double* nx, const double* ns,
+                                               const double* nc, double mu,
+                                               const double* area,
+                                               const double* cen, bool lower,
+                                               double sign, double* acc) {
+  double dist = 1.0, od[AGX_NEQ];
+  if (sp.viscous) {
+    // ProjC2CDist procBlock.cpp:6316-6342: (upper centre - lower centre) . n
+    const double sg = lower ? 1.0 : -1.0;
+    const double v[3] = {sg * (cen[0] - nc[0]), sg * (cen[1] - nc[1]),
+                         sg * (cen[2] - nc[2])};
+    dist = dot3(v, area);
+  }
+  off_diagonal(g, sp.viscous, ns, nx, area, mu, dist, lower, od);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) acc[e] += sign * od[e];
+}
+
+// everything one cell of the sweep reads from memory, fetched ONE STEP AHEAD so
+// that no load sits on the step-to-step dependency chain
+struct LusgsCell {
+  double x[AGX_NEQ], ainv, s[AGX_NEQ], rb[AGX_NEQ];   // rec_dyn
+  double c[3], area[3][4], mu;                         // rec_geo
+  LusgsNbr ob[3];          // sweep-side neighbours that lie outside the brick
+  int use, inside;         // bit d: neighbour d counts / comes from inside the brick
+};
+
+// direction D of lusgs_fetch (a template so that every struct member is
+// addressed with a compile-time index and stays in registers)
+template <bool FORWARD, int D>
+__device__ __forceinline__ void lusgs_fetch_dir(const BlockDev& b, const SolverDev& sp,
+                                                long q, int i, int j, int k, int lcd,
+                                                int lextd, LusgsCell& c) {
+  const int ccd = D == 0 ? i : (D == 1 ? j : k);
+  const int nnd = D == 0 ? b.ni : (D == 1 ? b.nj : b.nk);
+  const long strd = D == 0 ? 1 : (D == 1 ? b.sx : b.sxy);
+  const bool inside = FORWARD ? lcd > 0 : (lcd < lextd - 1 && ccd < nnd - 1);
+  const bool use = inside ||
+      (FORWARD ? (ccd > 0 || bc_is_connection(b, i, j, k, 2 * D + 1))
+               : (ccd < nnd - 1 ||
+                  bc_is_connection(b, i + (D == 0), j + (D == 1), k + (D == 2), 2 * D + 2)));
+  if (inside) c.inside |= 1 << D;
+  if (use) c.use |= 1 << D;
+  if (use && !inside)
+    lusgs_load_nbr<FORWARD>(b, sp.viscous, q + (FORWARD ? -strd : strd), D, c.ob[D]);
+}
+
+template <bool FORWARD>
+__device__ __forceinline__ void lusgs_fetch(const BlockDev& b, const SolverDev& sp,
+                                            int i0, int bi, int li, int lj, int lk, int j,
+                                            int k, LusgsCell& c) {
+  const int i = i0 + li;
+  const long q = b.idx(i, j, k);
+  double t[LREC];
+  lusgs_ld(b.rec_dyn + q * LREC, 0, 8, t);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) { c.x[e] = t[e]; c.s[e] = t[6 + e]; c.rb[e] = t[11 + e]; }
+  c.ainv = t[5];
+  lusgs_ld(b.rec_geo + q * LREC, 0, 8, t);
+  c.c[0] = t[0]; c.c[1] = t[1]; c.c[2] = t[2];
+  c.mu = t[15];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    c.area[0][m] = t[3 + m]; c.area[1][m] = t[7 + m]; c.area[2][m] = t[11 + m];
+  }
+  c.use = 0; c.inside = 0;
+  lusgs_fetch_dir<FORWARD, 0>(b, sp, q, i, j, k, li, bi, c);
+  lusgs_fetch_dir<FORWARD, 1>(b, sp, q, i, j, k, lj, 8, c);
+  lusgs_fetch_dir<FORWARD, 2>(b, sp, q, i, j, k, lk, 8, c);
+}
+
+// the triangle opposite to the sweep direction (matrixSweeps > 1 only), values
+// of the previous sweep read in place
+template <bool FORWARD, int D>
+__device__ __forceinline__ void lusgs_other_dir(const BlockDev& b, const GasDev& g,
+                                                const SolverDev& sp, long q, int i, int j,
+                                                int k, const double* own_area,
+                                                const double* cen, double* acc) {
+  const int ccd = D == 0 ? i : (D == 1 ? j : k);
+  const int nnd = D == 0 ? b.ni : (D == 1 ? b.nj : b.nk);
+  const long strd = D == 0 ? 1 : (D == 1 ? b.sx : b.sxy);
+  const bool use = !FORWARD
+      ? (ccd > 0 || bc_is_connection(b, i, j, k, 2 * D + 1))
+      : (ccd < nnd - 1 ||
+         bc_is_connection(b, i + (D == 0), j + (D == 1), k + (D == 2), 2 * D + 2));
+  if (!use) return;
+  LusgsNbr nb;
+  // neighbour on the far side: above for the forward sweep (its lower face is the
+  // shared one), below for the backward sweep (the own lower face is shared)
+  if (FORWARD) lusgs_load_nbr<false>(b, sp.viscous, q + strd, D, nb);
+  else lusgs_load_nbr<true>(b, sp.viscous, q - strd, D, nb);
+  lusgs_nbr_term(g, sp, nb.x, nb.s, nb.c, nb.mu, FORWARD ? nb.a : own_area, cen, !FORWARD,
+                 !FORWARD ? 1.0 : -1.0, acc);
+}
+
+template <bool FORWARD, int LBI>
+__global__ void __launch_bounds__(256)
+k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi, int nbj,
+              int nbk) {
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x * blockDim.y + threadIdx.y;   // wave-uniform
+  const int BJ = slot % nbj, BK = slot / nbj;
+  if (BK >= nbk) return;
+  const int BI = cplane - BJ - BK;
+  if (BI < 0 || BI >= nbi) return;
+  const int lj = lane & 7, lk = lane >> 3;
+  const int i0 = BI * LBI, j = BJ * 8 + lj, k = BK * 8 + lk;
+  const int bi = min(LBI, b.ni - i0);
+  const bool line = j < b.nj && k < b.nk;
+  const int nsteps = bi + min(8, b.nj - BJ * 8) + min(8, b.nk - BK * 8) - 2;
+  // fine-plane position of this lane's cell at step t
+  auto li_at = [&](int t) { return (FORWARD ? t : nsteps - 1 - t) - lj - lk; };
+  auto act_at = [&](int t) { const int l = li_at(t); return line && l >= 0 && l < bi; };
+  LusgsDone prev;                              // the cell this lane finished last
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) { prev.x[e] = 0.0; prev.s[e] = 1.0; }
+  prev.mu = 0.0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    prev.c[d] = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) prev.area[d][m] = 0.0;
+  }
+  // two cell buffers used alternately: one is consumed while the other is filled
+  LusgsCell ca, cb;
+  if (act_at(0)) lusgs_fetch<FORWARD>(b, sp, i0, bi, li_at(0), lj, lk, j, k, ca);
+  auto step = [&](int t, const LusgsCell& cur, LusgsCell& nxt) {
+    const int li = li_at(t);
+    const bool act = act_at(t);
+    if (t + 1 < nsteps && act_at(t + 1))
+      lusgs_fetch<FORWARD>(b, sp, i0, bi, li_at(t + 1), lj, lk, j, k, nxt);
+    // what the neighbouring lanes finished in the previous step
+    double jx[AGX_NEQ], js[AGX_NEQ], jc[3], ja[4], kx[AGX_NEQ], ks[AGX_NEQ], kc[3], ka[4];
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      jx[e] = FORWARD ? __shfl_up(prev.x[e], 1, 64) : __shfl_down(prev.x[e], 1, 64);
+      js[e] = FORWARD ? __shfl_up(prev.s[e], 1, 64) : __shfl_down(prev.s[e], 1, 64);
+      kx[e] = FORWARD ? __shfl_up(prev.x[e], 8, 64) : __shfl_down(prev.x[e], 8, 64);
+      ks[e] = FORWARD ? __shfl_up(prev.s[e], 8, 64) : __shfl_down(prev.s[e], 8, 64);
+    }
+    double jmu = 0.0, kmu = 0.0;
+    if (sp.viscous) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        jc[d] = FORWARD ? __shfl_up(prev.c[d], 1, 64) : __shfl_down(prev.c[d], 1, 64);
+        kc[d] = FORWARD ? __shfl_up(prev.c[d], 8, 64) : __shfl_down(prev.c[d], 8, 64);
+      }
+      jmu = FORWARD ? __shfl_up(prev.mu, 1, 64) : __shfl_down(prev.mu, 1, 64);
+      kmu = FORWARD ? __shfl_up(prev.mu, 8, 64) : __shfl_down(prev.mu, 8, 64);
+    }
+    if (!FORWARD) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        ja[m] = __shfl_down(prev.area[1][m], 1, 64);
+        ka[m] = __shfl_down(prev.area[2][m], 8, 64);
+      }
+    }
+    if (!act) return;
+    const int i = i0 + li;
+    const long q = b.idx(i, j, k);
+    double acc[AGX_NEQ] = {0, 0, 0, 0, 0};
+    const double sgn = FORWARD ? 1.0 : -1.0;
+    // sweep side (L for the forward sweep, U for the backward sweep); the face
+    // is the own lower face (forward) or the neighbour's lower face (backward)
+    if (cur.use & 1) {
+      const bool in = cur.inside & 1;
+      double nx[AGX_NEQ], ns[AGX_NEQ], nc[3], na[4];
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) {
+        nx[e] = in ? prev.x[e] : cur.ob[0].x[e];
+        ns[e] = in ? prev.s[e] : cur.ob[0].s[e];
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) nc[d] = in ? prev.c[d] : cur.ob[0].c[d];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        na[m] = FORWARD ? cur.area[0][m] : (in ? prev.area[0][m] : cur.ob[0].a[m]);
+      lusgs_nbr_term(g, sp, nx, ns, nc, in ? prev.mu : cur.ob[0].mu, na, cur.c, FORWARD,
+                     sgn, acc);
+    }
+    if (cur.use & 2) {
+      const bool in = cur.inside & 2;
+      double nx[AGX_NEQ], ns[AGX_NEQ], nc[3], na[4];
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) {
+        nx[e] = in ? jx[e] : cur.ob[1].x[e];
+        ns[e] = in ? js[e] : cur.ob[1].s[e];
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) nc[d] = in ? jc[d] : cur.ob[1].c[d];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        na[m] = FORWARD ? cur.area[1][m] : (in ? ja[m] : cur.ob[1].a[m]);
+      lusgs_nbr_term(g, sp, nx, ns, nc, in ? jmu : cur.ob[1].mu, na, cur.c, FORWARD, sgn,
+                     acc);
+    }
+    if (cur.use & 4) {
+      const bool in = cur.inside & 4;
+      double nx[AGX_NEQ], ns[AGX_NEQ], nc[3], na[4];
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) {
+        nx[e] = in ? kx[e] : cur.ob[2].x[e];
+        ns[e] = in ? ks[e] : cur.ob[2].s[e];
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) nc[d] = in ? kc[d] : cur.ob[2].c[d];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        na[m] = FORWARD ? cur.area[2][m] : (in ? ka[m] : cur.ob[2].a[m]);
+      lusgs_nbr_term(g, sp, nx, ns, nc, in ? kmu : cur.ob[2].mu, na, cur.c, FORWARD, sgn,
+                     acc);
+    }
+    double xn[AGX_NEQ];
+    if (full || FORWARD) {
+      if (full) {
+        lusgs_other_dir<FORWARD, 0>(b, g, sp, q, i, j, k, cur.area[0], cur.c, acc);
+        lusgs_other_dir<FORWARD, 1>(b, g, sp, q, i, j, k, cur.area[1], cur.c, acc);
+        lusgs_other_dir<FORWARD, 2>(b, g, sp, q, i, j, k, cur.area[2], cur.c, acc);
+      }
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) xn[e] = (cur.rb[e] + acc[e]) * cur.ainv;
+    } else {
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) xn[e] = cur.x[e] + acc[e] * cur.ainv;
+    }
+    double* r = b.rec_dyn + q * LREC;
+    reinterpret_cast<double2*>(r)[0] = make_double2(xn[0], xn[1]);
+    reinterpret_cast<double2*>(r)[1] = make_double2(xn[2], xn[3]);
+    r[4] = xn[4];
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) { prev.x[e] = xn[e]; prev.s[e] = cur.s[e]; }
+    prev.mu = cur.mu;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      prev.c[d] = cur.c[d];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) prev.area[d][m] = cur.area[d][m];
+    }
+  };
+  for (int t = 0; t < nsteps; t += 2) {
+    step(t, ca, cb);
+    if (t + 1 < nsteps) step(t + 1, cb, ca);
+  }
 }
 
 // dplur::DPLUR linearSolver.cpp:473-507 (point Jacobi on the copied xold)

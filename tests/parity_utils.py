@@ -6,6 +6,7 @@ from aither_amd.solver import Solver
 # fp64 tolerance stated by BASELINE.json north_star: residuals and updated
 # state within 1e-10 relative of the CPU reference.
 RTOL = 1.0e-10
+MATRIX_RTOL = 1.0e-6   # see run_pair: a cancellation remainder, not a field
 
 
 def rel_err(got, ref, floor=0.0):
@@ -72,7 +73,12 @@ def run_pair(agx, oracle, case, steps, fields=("state", "residual", "dt"),
             assert e < RTOL, ("L2 residual norm", hg["nn"], hg["mm"], e,
                               hg["l2"], ho["l2"])
             if ho["matrix"] > 0:
-                assert abs(hg["matrix"] - ho["matrix"]) <= 1e-8 * ho["matrix"], \
+                # The matrix residual f - (Ax - b) is what is LEFT after O(1)
+                # terms cancel (1e-7 per cell here against operands of 1e-3), so
+                # its own relative error is the 1e-10 parity of its operands (x,
+                # state, residual -- asserted below) times that cancellation
+                # factor; MATRIX_RTOL states the resulting bound.
+                assert abs(hg["matrix"] - ho["matrix"]) <= MATRIX_RTOL * ho["matrix"], \
                     ("matrix residual", hg["matrix"], ho["matrix"])
         n_hist = len(so.history)
         lg, lo = sg.history[-1]["linf"], so.history[-1]["linf"]

@@ -50,6 +50,27 @@ def test_free_running_drift(agx, oracle, name, steps):
     _close(sg, so)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ti", ["rk4", "explicitEuler"])
+def test_free_running_explicit_with_time_n(agx, oracle, ti):
+    """Explicit steps without resync: exercises the stage-0 launch that also
+    forms consVarsN (AssignSolToTimeN folded into the fused kernel) and the
+    deferred-store flush on download."""
+    kw = dict(n=(70, 9, 8), stretch=1.15, skew=0.01, time_integration=ti, cfl=0.5)
+    case = synthetic.single_block_case(**kw)
+    sg, so = Solver(agx, case), Solver(oracle, case)
+    for nn in range(3):
+        sg.step(nn), so.step(nn)
+    sg.store_time_n(3), so.store_time_n(3)      # left pending on the GPU side
+    ng = case.ng
+    for f in ("state", "cons_n", "residual", "dt"):
+        a, b = sg.download(f, 0), so.download(f, 0)
+        if f == "state":
+            a, b = a[ng:-ng, ng:-ng, ng:-ng], b[ng:-ng, ng:-ng, ng:-ng]
+        assert rel_err(a, b) < RTOL, f
+    _close(sg, so)
+
+
 # ---- synthetic 3-D cases: every scheme combination on the hot path ----------
 SLIP = None
 FARFIELD = {s: ("characteristic", 1) for s in range(1, 7)}
