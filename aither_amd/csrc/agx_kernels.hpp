@@ -1657,7 +1657,11 @@ __device__ __forceinline__ void lusgs_nbr_term(const GasDev& g, const SolverDev&
                                                const double* nc, double mu,
                                                const double* area,
                                                const double* cen, bool lower,
-                                               double sign, double* acc) {
+                                               double sign, bool use, double* acc) {
+  // branch-free on purpose: the three neighbour terms of a cell are independent
+  // instruction chains, and a lone wave per SIMD needs them in one basic block to
+  // overlap their latencies; `use` only selects at the end (inputs of an unused
+  // neighbour may be anything)
   double dist = 1.0, od[AGX_NEQ];
   if (sp.viscous) {
     // ProjC2CDist procBlock.cpp:6316-6342: (upper centre - lower centre) . n
@@ -1668,7 +1672,7 @@ __device__ __forceinline__ void lusgs_nbr_term(const GasDev& g, const SolverDev&
   }
   off_diagonal(g, sp.viscous, ns, nx, area, mu, dist, lower, od);
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) acc[e] += sign * od[e];
+  for (int e = 0; e < AGX_NEQ; ++e) acc[e] += use ? sign * od[e] : 0.0;
 }
 
 // everything one cell of the sweep reads from memory, fetched ONE STEP AHEAD so
@@ -1745,7 +1749,7 @@ __device__ __forceinline__ void lusgs_other_dir(const BlockDev& b, const GasDev&
   if (FORWARD) lusgs_load_nbr<false>(b, sp.viscous, q + strd, D, nb);
   else lusgs_load_nbr<true>(b, sp.viscous, q - strd, D, nb);
   lusgs_nbr_term(g, sp, nb.x, nb.s, nb.c, nb.mu, FORWARD ? nb.a : own_area, cen, !FORWARD,
-                 !FORWARD ? 1.0 : -1.0, acc);
+                 !FORWARD ? 1.0 : -1.0, true, acc);
 }
 
 template <bool FORWARD, int LBI>
@@ -1817,7 +1821,7 @@ k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi,
     const double sgn = FORWARD ? 1.0 : -1.0;
     // sweep side (L for the forward sweep, U for the backward sweep); the face
     // is the own lower face (forward) or the neighbour's lower face (backward)
-    if (cur.use & 1) {
+    {
       const bool in = cur.inside & 1;
       double nx[AGX_NEQ], ns[AGX_NEQ], nc[3], na[4];
 #pragma unroll
@@ -1831,9 +1835,9 @@ k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi,
       for (int m = 0; m < 4; ++m)
         na[m] = FORWARD ? cur.area[0][m] : (in ? prev.area[0][m] : cur.ob[0].a[m]);
       lusgs_nbr_term(g, sp, nx, ns, nc, in ? prev.mu : cur.ob[0].mu, na, cur.c, FORWARD,
-                     sgn, acc);
+                     sgn, cur.use & 1, acc);
     }
-    if (cur.use & 2) {
+    {
       const bool in = cur.inside & 2;
       double nx[AGX_NEQ], ns[AGX_NEQ], nc[3], na[4];
 #pragma unroll
@@ -1847,9 +1851,9 @@ k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi,
       for (int m = 0; m < 4; ++m)
         na[m] = FORWARD ? cur.area[1][m] : (in ? ja[m] : cur.ob[1].a[m]);
       lusgs_nbr_term(g, sp, nx, ns, nc, in ? jmu : cur.ob[1].mu, na, cur.c, FORWARD, sgn,
-                     acc);
+                     cur.use & 2, acc);
     }
-    if (cur.use & 4) {
+    {
       const bool in = cur.inside & 4;
       double nx[AGX_NEQ], ns[AGX_NEQ], nc[3], na[4];
 #pragma unroll
@@ -1863,7 +1867,7 @@ k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi,
       for (int m = 0; m < 4; ++m)
         na[m] = FORWARD ? cur.area[2][m] : (in ? ka[m] : cur.ob[2].a[m]);
       lusgs_nbr_term(g, sp, nx, ns, nc, in ? kmu : cur.ob[2].mu, na, cur.c, FORWARD, sgn,
-                     acc);
+                     cur.use & 4, acc);
     }
     double xn[AGX_NEQ];
     if (full || FORWARD) {
