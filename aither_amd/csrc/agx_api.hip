@@ -40,6 +40,8 @@ struct Block {
   int global_pos = 0;
   double* slab = nullptr;
   double* rec = nullptr;      // LU-SGS sweep records
+  int* pipe_mem = nullptr;    // k_lusgs_pipe: brick order | done flags | ticket
+  int pipe_total = 0, pipe_epoch = 0, pipe_lbi = 0;
   bool state_is_a = true;
   agx_bc_surface* surf_dev = nullptr;
   std::vector<agx_bc_surface> surf_host;
@@ -82,8 +84,8 @@ struct agx_ctx {
   bool use_gather = false;   // AGX_KERNEL=gather: one-thread-per-cell gather kernel
   bool use_tile = true;      // AGX_KERNEL=tile (default) | march
   int num_cu = 256;          // persistent workgroups of the tile kernel
-  bool lusgs_plane = false;  // AGX_LUSGS=plane: one launch per fine hyperplane
-  int lusgs_lbi = 16;        // brick length along i (AGX_LBI=8|16)
+  int lusgs_mode = 1;        // AGX_LUSGS=plane (0) | brick (1, default) | pipe (2)
+  int lusgs_lbi = 8;         // brick length along i (AGX_LBI=8|16)
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
   bool x_in_records = false;    // LU-SGS: newest x is in rec_dyn, SoA planes stale
@@ -287,8 +289,12 @@ double* const* halo_planes(Block& b, int what) {
 
 int check_device_error(agx_ctx* c) {
   if (*c->err_host) {
+    const int code = *c->err_host;
     *c->err_host = 0;
     hipMemsetAsync(c->err_dev, 0, sizeof(int), c->stream);
+    if (code == 2)
+      return fail("LU-SGS pipeline: a brick waited beyond the spin limit for its "
+                  "predecessors (AGX_LUSGS=brick selects the launch-per-plane form)");
     return fail("a boundary-condition variant outside this build's coverage "
                 "was requested (nonreflecting inlet/outlet or heat-flux wall)");
   }
@@ -410,8 +416,54 @@ int flush_x(agx_ctx* c) {
   HIPCHK(hipGetLastError());
   return 0;
 }
-void lusgs_sweep(agx_ctx* c, const BlockDev& b, bool forward, int full) {
-  if (c->lusgs_plane) {
+template <bool FWD, int LBI>
+int lusgs_pipe_launch(agx_ctx* c, Block& blk, int full) {
+  const BlockDev& b = blk.d;
+  const int nbi = (b.ni + LBI - 1) / LBI, nbj = (b.nj + 7) / 8, nbk = (b.nk + 7) / 8;
+  const int total = nbi * nbj * nbk;
+  if (!blk.pipe_mem || blk.pipe_lbi != LBI) {
+    // brick ids in coarse-plane order (any topological order would do)
+    std::vector<int> order;
+    order.reserve(total);
+    for (int p = 0; p <= nbi + nbj + nbk - 3; ++p)
+      for (int bk = 0; bk < nbk; ++bk)
+        for (int bj = 0; bj < nbj; ++bj) {
+          const int bi = p - bj - bk;
+          if (bi >= 0 && bi < nbi) order.push_back(bi + nbi * (bj + nbj * bk));
+        }
+    if (blk.pipe_mem) hipFree(blk.pipe_mem);
+    HIPCHK(hipMalloc((void**)&blk.pipe_mem, sizeof(int) * (2 * (size_t)total + 1)));
+    HIPCHK(hipMemcpyAsync(blk.pipe_mem, order.data(), sizeof(int) * total,
+                          hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));     // `order` is a stack vector
+    HIPCHK(hipMemsetAsync(blk.pipe_mem + total, 0, sizeof(int) * ((size_t)total + 1), c->stream));
+    blk.pipe_total = total; blk.pipe_epoch = 0; blk.pipe_lbi = LBI;
+  }
+  LusgsPipe pp;
+  pp.order = blk.pipe_mem;
+  pp.flags = blk.pipe_mem + total;
+  pp.ticket = blk.pipe_mem + 2 * total;
+  pp.err = c->err_dev;
+  pp.total = total;
+  pp.epoch = ++blk.pipe_epoch;
+  pp.spin_limit = getenv("AGX_SPIN_LIMIT") ? atoi(getenv("AGX_SPIN_LIMIT")) : 4000000;
+  HIPCHK(hipMemsetAsync(pp.ticket, 0, sizeof(int), c->stream));
+  // persistent: as many workgroups as are resident at once (the kernel's register
+  // use decides; asked from the runtime), never more than there are bricks
+  int per_cu = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &per_cu, reinterpret_cast<const void*>(&k_lusgs_pipe<FWD, LBI>), 256, 0) != hipSuccess ||
+      per_cu < 1)
+    per_cu = 1;
+  const int wgs = std::min(per_cu * c->num_cu, (total + 3) / 4);
+  hipLaunchKernelGGL((k_lusgs_pipe<FWD, LBI>), dim3(wgs), dim3(64, 4), 0, c->stream, b,
+                     c->gas, c->sp, full, nbi, nbj, nbk, pp);
+  return 0;
+}
+
+int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full) {
+  const BlockDev& b = blk.d;
+  if (c->lusgs_mode == 0) {
     const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
     const int nplanes = b.ni + b.nj + b.nk - 2;
     for (int t = 0; t < nplanes; ++t) {
@@ -423,11 +475,18 @@ void lusgs_sweep(agx_ctx* c, const BlockDev& b, bool forward, int full) {
         hipLaunchKernelGGL((k_lusgs_plane<false>), grid, tb, 0, c->stream, b, c->gas,
                            c->sp, p, full);
     }
-    return;
+    return 0;
   }
   if (!c->x_in_records)
     hipLaunchKernelGGL(k_lusgs_pack, dim3((b.nplane + 255) / 256), dim3(256), 0, c->stream,
                        b, c->gas, c->sp);
+  if (c->lusgs_mode == 2) {
+    if (c->lusgs_lbi == 8)
+      return forward ? lusgs_pipe_launch<true, 8>(c, blk, full)
+                     : lusgs_pipe_launch<false, 8>(c, blk, full);
+    return forward ? lusgs_pipe_launch<true, 16>(c, blk, full)
+                   : lusgs_pipe_launch<false, 16>(c, blk, full);
+  }
   if (c->lusgs_lbi == 8) {
     if (forward) lusgs_brick_launches<true, 8>(c, b, full);
     else lusgs_brick_launches<false, 8>(c, b, full);
@@ -435,6 +494,7 @@ void lusgs_sweep(agx_ctx* c, const BlockDev& b, bool forward, int full) {
     if (forward) lusgs_brick_launches<true, 16>(c, b, full);
     else lusgs_brick_launches<false, 16>(c, b, full);
   }
+  return 0;
 }
 
 // consVarsN = cons(state) that agx_store_time_n deferred (see there)
@@ -565,8 +625,9 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
     if (ncu > 0) c->num_cu = ncu;
     if (const char* w = getenv("AGX_WORKGROUPS")) c->num_cu = std::max(1, atoi(w));
-    if (const char* w = getenv("AGX_LUSGS")) c->lusgs_plane = !strcmp(w, "plane");
-    if (const char* w = getenv("AGX_LBI")) c->lusgs_lbi = atoi(w) == 8 ? 8 : 16;
+    if (const char* w = getenv("AGX_LUSGS"))
+      c->lusgs_mode = !strcmp(w, "plane") ? 0 : (!strcmp(w, "pipe") ? 2 : 1);
+    if (const char* w = getenv("AGX_LBI")) c->lusgs_lbi = atoi(w) == 16 ? 16 : 8;
   }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
   HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
@@ -583,6 +644,7 @@ void agx_ctx_destroy(agx_ctx* c) {
   for (auto& b : c->blocks) {
     if (b.slab) hipFree(b.slab);
     if (b.rec) hipFree(b.rec);
+    if (b.pipe_mem) hipFree(b.pipe_mem);
     if (b.surf_dev) hipFree(b.surf_dev);
   }
   for (auto& k : c->conns) {
@@ -910,7 +972,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
     if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
-      lusgs_sweep(c, b, true, full);
+      if (lusgs_sweep(c, blk, true, full)) return 1;
       swept = true;
     } else {
       hipLaunchKernelGGL(k_copy5, dim3((b.nplane + 255) / 256), dim3(256), 0,
@@ -919,7 +981,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
                          c->stream, b, c->gas, c->sp);
     }
   }
-  if (swept && !c->lusgs_plane) c->x_in_records = true;
+  if (swept && c->lusgs_mode != 0) c->x_in_records = true;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -929,10 +991,9 @@ int agx_phase_relax_backward(agx_ctx* c, int sweep) {
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
   for (auto& blk : c->blocks) {
-    const BlockDev& b = blk.d;
-    lusgs_sweep(c, b, false, full);
+    if (lusgs_sweep(c, blk, false, full)) return 1;
   }
-  if (!c->lusgs_plane) c->x_in_records = true;
+  if (c->lusgs_mode != 0) c->x_in_records = true;
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -1752,16 +1752,12 @@ __device__ __forceinline__ void lusgs_other_dir(const BlockDev& b, const GasDev&
                  !FORWARD ? 1.0 : -1.0, true, acc);
 }
 
+// one brick, one wave
 template <bool FORWARD, int LBI>
-__global__ void __launch_bounds__(256)
-k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi, int nbj,
-              int nbk) {
+__device__ __forceinline__ void lusgs_brick_body(const BlockDev& b, const GasDev& g,
+                                                 const SolverDev& sp, int full, int BI,
+                                                 int BJ, int BK) {
   const int lane = threadIdx.x;
-  const int slot = blockIdx.x * blockDim.y + threadIdx.y;   // wave-uniform
-  const int BJ = slot % nbj, BK = slot / nbj;
-  if (BK >= nbk) return;
-  const int BI = cplane - BJ - BK;
-  if (BI < 0 || BI >= nbi) return;
   const int lj = lane & 7, lk = lane >> 3;
   const int i0 = BI * LBI, j = BJ * 8 + lj, k = BK * 8 + lk;
   const int bi = min(LBI, b.ni - i0);
@@ -1899,6 +1895,88 @@ k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi,
   for (int t = 0; t < nsteps; t += 2) {
     step(t, ca, cb);
     if (t + 1 < nsteps) step(t + 1, cb, ca);
+  }
+}
+
+// (a) one launch per coarse hyperplane (default): every wave takes the brick
+//     (BJ, BK) of plane `cplane`
+template <bool FORWARD, int LBI>
+__global__ void __launch_bounds__(256)
+k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi, int nbj,
+              int nbk) {
+  const int slot = blockIdx.x * blockDim.y + threadIdx.y;   // wave-uniform
+  const int BJ = slot % nbj, BK = slot / nbj;
+  if (BK >= nbk) return;
+  const int BI = cplane - BJ - BK;
+  if (BI < 0 || BI >= nbi) return;
+  lusgs_brick_body<FORWARD, LBI>(b, g, sp, full, BI, BJ, BK);
+}
+
+// (b) ONE launch per half sweep (AGX_LUSGS=pipe): persistent waves draw bricks
+//     from a ticket counter in coarse-plane order and start a brick as soon as
+//     its three predecessor bricks have published their `done` flag, so the
+//     bricks of successive coarse planes overlap instead of waiting for a whole
+//     plane.  Measured 10 % faster than (a) at 256^3 (the chain of 94 dependent
+//     bricks stays the critical path either way), so (a), which needs no
+//     inter-workgroup protocol, is the default.
+//     Progress: a ticket is only ever held by a running wave and every
+//     predecessor of a brick has a smaller ticket, so the wave holding the
+//     smallest unfinished ticket never waits -- no dependence on dispatch order.
+//     Every wave leaves the loop when the tickets run out; a wave that spins
+//     longer than `spin_limit` polls raises *err and all waves drain.
+//     Visibility across CUs / XCDs: agent-scope release fence before the flag
+//     store, agent-scope acquire fence after the flag loads.
+struct LusgsPipe {
+  const int* order;     // ticket -> packed brick id (BI + nbi * (BJ + nbj * BK))
+  int* flags;           // per brick: epoch of the half sweep that completed it
+  int* ticket;
+  int* err;
+  int total, epoch, spin_limit;
+};
+template <bool FORWARD, int LBI>
+__global__ void __launch_bounds__(256)
+k_lusgs_pipe(BlockDev b, GasDev g, SolverDev sp, int full, int nbi, int nbj, int nbk,
+             LusgsPipe pp) {
+  // Every lane executes the same scalar protocol on the same addresses (the
+  // hardware merges them): no lane-0-only control flow for the compiler to
+  // restructure, and the loop exits are uniform by construction.
+  const int lane = threadIdx.x;
+  for (;;) {
+    int t = atomicAdd(pp.ticket, lane == 0 ? 1 : 0);
+    t = __shfl(t, 0, 64);
+    if (t >= pp.total) break;
+    int id = pp.order[FORWARD ? t : pp.total - 1 - t];
+    id = __builtin_amdgcn_readfirstlane(id);
+    const int BI = id % nbi, BJ = (id / nbi) % nbj, BK = id / (nbi * nbj);
+    // predecessors on the sweep side
+    const int sd = FORWARD ? -1 : 1;
+    const int pi = BI + sd, pj = BJ + sd, pk = BK + sd;
+    const int pre[3] = {(pi >= 0 && pi < nbi) ? pi + nbi * (BJ + nbj * BK) : -1,
+                        (pj >= 0 && pj < nbj) ? BI + nbi * (pj + nbj * BK) : -1,
+                        (pk >= 0 && pk < nbk) ? BI + nbi * (BJ + nbj * pk) : -1};
+    bool ok = true;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      if (pre[m] < 0 || !ok) continue;
+      int spins = 0;
+      while (__hip_atomic_load(pp.flags + pre[m], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT) != pp.epoch) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > pp.spin_limit ||
+            __hip_atomic_load(pp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          ok = false;
+          break;
+        }
+      }
+    }
+    if (!ok) {
+      __hip_atomic_store(pp.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    lusgs_brick_body<FORWARD, LBI>(b, g, sp, full, BI, BJ, BK);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(pp.flags + id, pp.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
