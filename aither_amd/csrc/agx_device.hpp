@@ -221,15 +221,13 @@ __device__ __forceinline__ void weno_coeffs(const double* cw, WenoCoeffs& k) {
 }
 // Derivative2nd utility.hpp:114-120, BetaIntegral / Beta0/1/2
 // reconstruction.hpp:158-240
-__device__ __forceinline__ double beta_int(double d1, double d2, double dx,
-                                           double xl, double xh) {
-  const double dx3 = dx * dx * dx;
-  const double third = 1.0 / 3.0;
-  const double fh = (d1 * d1 * xh + d1 * d2 * xh * xh +
-                     d2 * d2 * (xh * xh * xh) * third) * dx + d2 * d2 * xh * dx3;
-  const double fl = (d1 * d1 * xl + d1 * d2 * xl * xl +
-                     d2 * d2 * (xl * xl * xl) * third) * dx + d2 * d2 * xl * dx3;
-  return fh - fl;
+// BetaIntegral reconstruction.hpp:158-183 evaluated between xl = -dx/2 and
+// xh = +dx/2 (the only limits Beta0/1/2 use): the terms odd in x cancel exactly
+// (xh^2 == xl^2 in floating point too), leaving
+//   dx^2 (d1^2 + 13/12 d2^2 dx^2)
+__device__ __forceinline__ double beta_int(double d1, double d2, double dx) {
+  const double dx2 = dx * dx;
+  return dx2 * (d1 * d1 + (13.0 / 12.0) * (d2 * d2) * dx2);
 }
 // ih21 = 1 / (0.5 (x2 + x1)), ih10 = 1 / (0.5 (x1 + x0)), iq = 1 / (0.25 (x2 + x0) + 0.5 x1)
 __device__ __forceinline__ double deriv2(double ih10, double ih21, double iq,
@@ -249,17 +247,17 @@ __device__ __forceinline__ double weno(const WenoCoeffs& k, const double* cw,
   {
     const double dd = deriv2(k.ih[0], k.ih[1], k.iq[0], u3, u2, u1);
     const double df = (u1 - u2) * k.ih[1] + 0.5 * cw[2] * dd;
-    b0 = beta_int(df, dd, cw[2], -0.5 * cw[2], 0.5 * cw[2]);
+    b0 = beta_int(df, dd, cw[2]);
   }
   {
     const double dd = deriv2(k.ih[1], k.ih[2], k.iq[1], u2, u1, d1);
     const double df = (d1 - u1) * k.ih[2] - 0.5 * cw[2] * dd;
-    b1 = beta_int(df, dd, cw[2], -0.5 * cw[2], 0.5 * cw[2]);
+    b1 = beta_int(df, dd, cw[2]);
   }
   {
     const double dd = deriv2(k.ih[2], k.ih[3], k.iq[2], u1, d1, d2);
     const double df = (d1 - u1) * k.ih[2] - 0.5 * cw[2] * dd;
-    b2 = beta_int(df, dd, cw[2], -0.5 * cw[2], 0.5 * cw[2]);
+    b2 = beta_int(df, dd, cw[2]);
   }
   double n0, n1, n2;
   if (WENOZ) {

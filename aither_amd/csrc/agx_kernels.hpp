@@ -493,21 +493,31 @@ __device__ __forceinline__ void recon_generic(Get get, GetW getw, double kappa,
       r[e] = muscl<LIM>(up, u0, u1, dPr, dMr, kappa);
     }
   } else {
-    double w[6];
+    // one side at a time: the width-only coefficient set of a side is 19
+    // doubles, and holding both sets across the variable loop is what drove
+    // this path into scratch
+    {
+      double cw[5];
 #pragma unroll
-    for (int m = 0; m < 6; ++m) w[m] = getw(m - 3);
-    const double cwl[5] = {w[0], w[1], w[2], w[3], w[4]};
-    const double cwr[5] = {w[5], w[4], w[3], w[2], w[1]};
-    WenoCoeffs kl, kr;
-    weno_coeffs(cwl, kl);
-    weno_coeffs(cwr, kr);
+      for (int m = 0; m < 5; ++m) cw[m] = getw(m - 3);
+      WenoCoeffs kc;
+      weno_coeffs(cw, kc);
 #pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) {
-      double u[6];
+      for (int e = 0; e < AGX_NEQ; ++e)
+        l[e] = weno<RECON == AGX_RECON_WENOZ>(kc, cw, get(e, -3), get(e, -2), get(e, -1),
+                                              get(e, 0), get(e, 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      double cw[5];
 #pragma unroll
-      for (int m = 0; m < 6; ++m) u[m] = get(e, m - 3);
-      l[e] = weno<RECON == AGX_RECON_WENOZ>(kl, cwl, u[0], u[1], u[2], u[3], u[4]);
-      r[e] = weno<RECON == AGX_RECON_WENOZ>(kr, cwr, u[5], u[4], u[3], u[2], u[1]);
+      for (int m = 0; m < 5; ++m) cw[m] = getw(2 - m);
+      WenoCoeffs kc;
+      weno_coeffs(cw, kc);
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e)
+        r[e] = weno<RECON == AGX_RECON_WENOZ>(kc, cw, get(e, 2), get(e, 1), get(e, 0),
+                                              get(e, -1), get(e, -2));
     }
   }
 }
