@@ -84,6 +84,7 @@ struct agx_ctx {
   bool use_gather = false;   // AGX_KERNEL=gather: one-thread-per-cell gather kernel
   bool use_tile = true;      // AGX_KERNEL=tile (default) | march
   int num_cu = 256;          // persistent workgroups of the tile kernel
+  bool visc_gather = false;  // AGX_VISC=gather: one-thread-per-cell viscous kernel
   int lusgs_mode = 1;        // AGX_LUSGS=plane (0) | brick (1, default) | pipe (2)
   int lusgs_lbi = 8;         // brick length along i (AGX_LBI=8|16)
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
@@ -625,6 +626,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
     if (ncu > 0) c->num_cu = ncu;
     if (const char* w = getenv("AGX_WORKGROUPS")) c->num_cu = std::max(1, atoi(w));
+    if (const char* w = getenv("AGX_VISC")) c->visc_gather = !strcmp(w, "gather");
     if (const char* w = getenv("AGX_LUSGS"))
       c->lusgs_mode = !strcmp(w, "plane") ? 0 : (!strcmp(w, "pipe") ? 2 : 1);
     if (const char* w = getenv("AGX_LBI")) c->lusgs_lbi = atoi(w) == 16 ? 16 : 8;
@@ -938,8 +940,18 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
     }
     Timer t(c, G_RESID);
     for (auto& blk : c->blocks)
-      hipLaunchKernelGGL(k_visc_residual, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
-                         0, c->stream, blk.d, c->gas, c->sp, cfl);
+      if (c->visc_gather) {
+        hipLaunchKernelGGL(k_visc_residual, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
+                           0, c->stream, blk.d, c->gas, c->sp, cfl);
+      } else {
+        const BlockDev& vb = blk.d;
+        const int gx = (vb.ni + VTI - 1) / VTI, gy = (vb.nj + VTJ - 1) / VTJ;
+        int nz = std::max(1, std::min(vb.nk / 8, (int)std::lround(2048.0 / (gx * gy))));
+        const int kchunk = (vb.nk + nz - 1) / nz;
+        nz = (vb.nk + kchunk - 1) / kchunk;
+        hipLaunchKernelGGL(k_visc_march, dim3(gx, gy, nz), dim3(64, VTJ + 1), 0, c->stream,
+                           vb, c->gas, c->sp, cfl, kchunk);
+      }
     HIPCHK(hipGetLastError());
   }
   return 0;

@@ -1103,6 +1103,77 @@ k_visc_residual(BlockDev b, GasDev g, SolverDev sp, double cfl) {
   b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (vol / fmax(sr, 0.0));
 }
 
+// Face-once form of k_visc_residual (production): a workgroup of 64 x 8 threads
+// owns a 63 x 7 column of cells and marches it along k.  Every thread evaluates
+// the viscous flux of its lower i-, lower j- and upper k-face; the upper i-face
+// comes from lane + 1 (wave shuffle), the upper j-face from the row above (LDS),
+// the lower k-face is the upper one of the previous step (registers).  Lane 63 and
+// row 7 are helpers that only produce the faces their neighbours need, so each
+// face flux (gradient stencil of ten cells) is formed once instead of twice.
+constexpr int VTI = 63, VTJ = 7;
+__global__ void __launch_bounds__(512)
+k_visc_march(BlockDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
+  __shared__ double sFj[2][VTJ + 1][AGX_NEQ][64];
+  const int lane = threadIdx.x, ty = threadIdx.y;
+  const int i = blockIdx.x * VTI + lane, j = blockIdx.y * VTJ + ty;
+  const int k0 = blockIdx.z * kchunk, k1 = min(k0 + kchunk, b.nk);
+  const bool own = lane < VTI && ty < VTJ && i < b.ni && j < b.nj;
+  const bool do_i = i <= b.ni && j < b.nj && ty < VTJ;      // lower i-face exists
+  const bool do_j = j <= b.nj && i < b.ni && lane < VTI;    // lower j-face exists
+  const int ic = min(i, b.ni), jc = min(j, b.nj);
+  long q = b.idx(ic, jc, k0);
+  const long sk = b.sxy;
+  double fk_lo[AGX_NEQ] = {0, 0, 0, 0, 0};
+  if (own) visc_face(b, g, 2, q, fk_lo);
+  int cur = 0;
+  for (int k = k0; k < k1; ++k, q += sk, cur ^= 1) {
+    double fi[AGX_NEQ] = {0, 0, 0, 0, 0}, fj[AGX_NEQ] = {0, 0, 0, 0, 0};
+    double fk_up[AGX_NEQ] = {0, 0, 0, 0, 0};
+    if (do_i) visc_face(b, g, 0, q, fi);
+    if (do_j) visc_face(b, g, 1, q, fj);
+    if (own) visc_face(b, g, 2, q + sk, fk_up);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) sFj[cur][ty][e][lane] = fj[e];
+    double fi_up[AGX_NEQ];
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) fi_up[e] = __shfl_down(fi[e], 1, 64);
+    __syncthreads();
+    if (own) {
+      double res[AGX_NEQ];
+      load5(b.resid, q, res);
+      // same accumulation order as the gather form: +lower -upper per direction
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) {
+        res[e] += fi[e];
+        res[e] -= fi_up[e];
+        res[e] += fj[e];
+        res[e] -= sFj[cur][ty + 1][e][lane];
+        res[e] += fk_lo[e];
+        res[e] -= fk_up[e];
+        fk_lo[e] = fk_up[e];
+      }
+      double sc[AGX_NEQ];
+      load5(b.state, q, sc);
+      const double muc = viscosity(g, temperature(g, sc));
+      const double vol = b.vol[q];
+      double sr = b.specrad[q];
+      double diag = sp.implicit ? b.a[q] : 0.0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        // ViscCellSpectralRadius spectralRadius.hpp:94-124
+        const double fmag = 0.5 * (b.fa[d][3][q] + b.fa[d][3][q + b.stride(d)]);
+        const double vsr = visc_max_term(g, sc[0]) * visc_term(g, muc) * fmag * fmag / vol;
+        sr += vsr * sp.visc_cfl_coeff;
+        diag += 2.0 * vsr;
+      }
+      store5(b.resid, q, res);
+      b.specrad[q] = sr;
+      if (sp.implicit) b.a[q] = diag;
+      b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (vol / fmax(sr, 0.0));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // boundary conditions
 // boundaryConditions::GetBCSurface boundaryConditions.cpp:109-170
