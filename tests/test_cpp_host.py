@@ -1,0 +1,134 @@
+"""The C++ host layer (include/aither_gfx950.hpp) driving the C-ABI.
+
+tests/cpp/host_parity.cpp is the reference-language statement of the time loop
+(main.cpp:232-275 reduced to StoreOldSolution + Iterate).  It is built twice,
+against the product library and against the CPU oracle; this module writes the
+case file both read and compares what they produce.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from parity_utils import rel_err, RTOL
+from aither_amd import abi
+from aither_amd.case import builder as _b
+from aither_amd.case import synthetic
+from aither_amd.solver import Solver
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CPP = os.path.join(HERE, "cpp")
+
+
+def build_drivers():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "..", "oracle")],
+                          stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CPP], stdout=subprocess.DEVNULL)
+
+
+def write_case_file(case, path, n_steps):
+    d = case.deck
+    cfg = _b.config_struct(case)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<7i", 0x31584741, len(case.blocks), len(case.connections),
+                            d.nonlinear_iterations, n_steps,
+                            int(d.need_to_store_time_n()),
+                            int(d.is_multilevel_in_time())))
+        f.write(np.array([d.cfl(nn) for nn in range(n_steps)], dtype="<f8").tobytes())
+        f.write(bytes(cfg))
+        for gb, blk in enumerate(case.blocks):
+            g = blk.geom
+            f.write(struct.pack("<6i", g.ni, g.nj, g.nk, g.ng, blk.parent, blk.global_pos))
+            for a in (g.farea["i"].a, g.farea["j"].a, g.farea["k"].a, g.vol.a,
+                      g.center.a, g.width["i"].a, g.width["j"].a, g.width["k"].a,
+                      g.wall_dist.a):
+                f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+            surfs = _b.surface_structs(case, gb)
+            f.write(struct.pack("<i", len(surfs)))
+            f.write(bytes(surfs))
+            f.write(np.ascontiguousarray(blk.state, dtype="<f8").tobytes())
+        for conn in case.connections:
+            cs = _b.connection_struct(conn)
+            for side in range(2):
+                cs.local_block[side] = conn.block[side]
+            f.write(bytes(cs))
+
+
+def read_output(case, path, n_steps):
+    n_eq, nonlin = 5, case.deck.nonlinear_iterations
+    raw = open(path, "rb").read()
+    rec = n_eq * 8 + 16 + 20
+    hist, off = [], 0
+    for _ in range(n_steps * nonlin):
+        l2 = np.frombuffer(raw, "<f8", n_eq, off)
+        linf, matrix = np.frombuffer(raw, "<f8", 2, off + n_eq * 8)
+        loc = np.frombuffer(raw, "<i4", 5, off + n_eq * 8 + 16)
+        hist.append((l2.copy(), float(linf), float(matrix), tuple(int(v) for v in loc)))
+        off += rec
+    states = []
+    for blk in case.blocks:
+        n = blk.state.size
+        states.append(np.frombuffer(raw, "<f8", n, off).reshape(blk.state.shape).copy())
+        off += n * 8
+    assert off == len(raw)
+    return hist, states
+
+
+CASES = {
+    "rk4_muscl_roe": dict(n=(20, 9, 8), stretch=1.15, skew=0.01, time_integration="rk4",
+                          cfl=0.5),
+    "lusgs_viscous": dict(n=(12, 10, 9), stretch=1.1, equation_set="navierStokes",
+                          time_integration="implicitEuler", matrix_solver="lusgs",
+                          cfl=5.0, bcs={3: ("viscousWall", 2), 1: ("characteristic", 1),
+                                        2: ("characteristic", 1), 4: ("characteristic", 1)}),
+}
+
+
+def _run(driver, case_file, out_file):
+    subprocess.check_call([os.path.join(CPP, driver), case_file, out_file], timeout=300)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_cpp_host_oracle_matches_python_host(oracle, tmp_path, name):
+    """Same library (the oracle), two hosts: the C++ layer must reproduce what
+    the Python plumbing gets, bit for bit."""
+    build_drivers()
+    case = synthetic.single_block_case(**CASES[name])
+    cf, of = str(tmp_path / "case.bin"), str(tmp_path / "ora.bin")
+    write_case_file(case, cf, 3)
+    _run("host_parity_ora", cf, of)
+    hist, states = read_output(case, of, 3)
+    s = Solver(oracle, case)
+    k = 0
+    for nn in range(3):
+        s.store_time_n(nn)
+        for mm in range(case.deck.nonlinear_iterations):
+            l2, linf, mres = s.iterate(mm, case.deck.cfl(nn))
+            assert np.array_equal(l2, hist[k][0])
+            assert linf.linf == hist[k][1] and mres == hist[k][2]
+            assert (linf.block, linf.i, linf.j, linf.k, linf.eqn) == hist[k][3]
+            k += 1
+    assert np.array_equal(s.download("state", 0), states[0])
+    s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_cpp_host_gpu_vs_oracle(tmp_path, name):
+    """The C++ host over libaither_gfx950.so against the C++ host over the oracle."""
+    build_drivers()
+    case = synthetic.single_block_case(**CASES[name])
+    cf = str(tmp_path / "case.bin")
+    write_case_file(case, cf, 3)
+    _run("host_parity_agx", cf, str(tmp_path / "agx.bin"))
+    _run("host_parity_ora", cf, str(tmp_path / "ora.bin"))
+    hg, sg = read_output(case, str(tmp_path / "agx.bin"), 3)
+    ho, so = read_output(case, str(tmp_path / "ora.bin"), 3)
+    ng = case.ng
+    for (l2g, _, _, _), (l2o, _, _, _) in zip(hg, ho):
+        assert rel_err(l2g[None, :], l2o[None, :]) < RTOL
+    for a, b in zip(sg, so):
+        assert rel_err(a[ng:-ng, ng:-ng, ng:-ng], b[ng:-ng, ng:-ng, ng:-ng]) < RTOL
