@@ -528,6 +528,7 @@ __global__ void __launch_bounds__(64 * (TJ + 2), 2)
 k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
   constexpr int H = RECON == AGX_RECON_CONSTANT ? 1
                     : (RECON == AGX_RECON_MUSCL ? 2 : 3);
+  constexpr bool BAL = TJ >= 4;   // SIMD load balancing, see the j-face block
   constexpr int NV = AGX_NEQ + 2;                 // state + wid_i + wid_j
   constexpr int TW = 64 + 2 * H, TR = TJ + 2 * H;
   constexpr int NW = TJ + 2;
@@ -724,8 +725,16 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      // ---- j face (lower): handed to the row below through LDS ----
-      if (cell) {
+      // ---- j face (lower): handed to the row below through LDS.  Rows 0 and 1
+      // leave this flux to the two halo waves (BAL): the cell waves of those rows
+      // share a SIMD with another cell wave, the halo waves with one only, and
+      // this evens the four SIMDs out at five flux evaluations each. ----
+      if (cell && BAL && wv < 2) {
+        double aj_lo[4], aj_up[4];
+        b.area(1, q, aj_lo);
+        b.area(1, q + b.sx, aj_up);
+        sr_j = AGX_AB(16) ? 1.0 : specrad(aj_lo, aj_up);
+      } else if (cell) {
         double l[AGX_NEQ], r[AGX_NEQ], f[AGX_NEQ], aj_lo[4], aj_up[4];
         b.area(1, q, aj_lo);
         b.area(1, q + b.sx, aj_up);
@@ -768,6 +777,10 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         cn[e] = (FUSE == 1 && ma.mode != 0) ? b.pl(PL_CONSN + e)[q] : 0.0;
       __syncthreads();
       if (cell) {
+        if (BAL && wv < 2) {
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) res[e] -= sFj[cur][wv][e][lane];
+        }
 #pragma unroll
         for (int e = 0; e < AGX_NEQ; ++e) res[e] += sFj[cur][wv + 1][e][lane];
         if (i == itop - 1) {
@@ -913,6 +926,21 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
           inviscid_flux<FLUX>(g, l, r, af, f);
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) sFi[cur][lane][e] = f[e] * af[3];
+        }
+      }
+      if (BAL) {
+        // lower j-face flux of cell row 0 (top wave) / 1 (right wave)
+        const int orow = top ? 0 : 1;
+        if (i0 + lane < itop && j0 + orow < jtop) {
+          double ao[4], l[AGX_NEQ], r[AGX_NEQ], f[AGX_NEQ];
+          b.area(1, b.idx(i0 + lane, j0 + orow, k), ao);
+          const double* base = tc + (orow + H) * TW + lane + H;
+          recon_generic<RECON, LIM>(
+              [&](int e, int m) { return base[e * PLANE + m * TW]; },
+              [&](int m) { return base[(AGX_NEQ + 1) * PLANE + m * TW]; }, sp.kappa, l, r);
+          inviscid_flux<FLUX>(g, l, r, ao, f);
+#pragma unroll
+          for (int e = 0; e < AGX_NEQ; ++e) sFj[cur][orow][e][lane] = f[e] * ao[3];
         }
       }
 #pragma unroll
