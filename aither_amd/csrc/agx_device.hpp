@@ -157,7 +157,8 @@ __device__ __forceinline__ double muscl(double uw2, double uw1, double dw1,
     lim = 1.0;
     rinv = fast_div(num, den);
   }
-  return uw1 + 0.25 * dm * ((1.0 - kappa) * lim + (1.0 + kappa) * rinv);
+  // 0.25 (1 -+ kappa) are wave-uniform scalars
+  return uw1 + dm * ((0.25 * (1.0 - kappa)) * lim + (0.25 * (1.0 + kappa)) * rinv);
 }
 
 // ---- WENO5 on non-uniform widths, reconstruction.hpp:158-310 --------------
