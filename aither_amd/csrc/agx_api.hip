@@ -304,10 +304,19 @@ int check_device_error(agx_ctx* c) {
 
 struct MarchPlan { dim3 grid; int kchunk; long nparts; };
 int g_march_tj = 6;   // cell rows per workgroup (512 threads)
+// the tile kernel addresses a plane with 32-bit byte offsets (SlabDev::ldb)
+bool tile_ok(const agx_ctx* c, const BlockDev& b) {
+  return c->use_tile && !c->use_gather && (double)b.nplane * 8.0 < 4294967296.0;
+}
+bool all_tile_ok(const agx_ctx* c) {
+  for (const auto& blk : c->blocks)
+    if (!tile_ok(c, blk.d)) return false;
+  return true;
+}
 MarchPlan march_plan(const agx_ctx* c, const BlockDev& b) {
   MarchPlan p;
   const int gx = (b.ni + 63) / 64, gy = (b.nj + g_march_tj - 1) / g_march_tj;
-  if (c->use_tile && !c->use_gather) {
+  if (tile_ok(c, b)) {
     // persistent workgroups, one per CU (LDS allows no more); small blocks get
     // fewer so that a range is at least ~8 steps long
     const long steps = (long)gx * gy * b.nk;
@@ -343,7 +352,7 @@ void launch_inv_kernel(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
     return;
   }
   const dim3 tb(64, g_march_tj + 2);
-  if (c->use_tile) {
+  if (tile_ok(c, b)) {
     if (fuse && ma.store_consn)
       hipLaunchKernelGGL((k_residual_tile<RECON, LIM, FLUX, 2, 6>), mp.grid, tb, 0,
                          c->stream, sd, c->gas, c->sp, cfl, ma);
@@ -893,7 +902,7 @@ int agx_store_time_n(agx_ctx* c, int also_nm1) {
   // separate 5-load/5-store pass); anything else that touches consVarsN or the
   // state first calls flush_consn().
   static const bool lazy = !(getenv("AGX_NO_LAZY_CONSN") && atoi(getenv("AGX_NO_LAZY_CONSN")));
-  if (lazy && !also_nm1 && can_fuse(c) && c->use_tile) { c->consn_pending = true; return 0; }
+  if (lazy && !also_nm1 && can_fuse(c) && all_tile_ok(c)) { c->consn_pending = true; return 0; }
   for (auto& blk : c->blocks)
     hipLaunchKernelGGL(k_store_time_n, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
                        0, c->stream, blk.d, c->gas, also_nm1);
@@ -909,7 +918,7 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
   if (c->cfg.dt_nondim <= 0.0 && cfl <= 0.0)
     return fail("Neither dt or cfl was specified!");   // procBlock.cpp:813-816
   const bool fuse = can_fuse(c);
-  const int store_consn = fuse && c->use_tile && c->consn_pending && mm == 0;
+  const int store_consn = fuse && all_tile_ok(c) && c->consn_pending && mm == 0;
   if (store_consn) c->consn_pending = false;
   else if (flush_consn(c)) return 1;
   {

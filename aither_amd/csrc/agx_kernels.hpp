@@ -73,6 +73,19 @@ struct SlabDev {               // compact view used by the marching kernel
 #pragma unroll
     for (int c = 0; c < 4; ++c) a[c] = fa(d, c)[q];
   }
+  // 32-bit BYTE offsets inside a plane (host guarantees nplane * 8 < 2^32): the
+  // address is a wave-uniform plane base plus one VGPR, so the loads use the
+  // SGPR-base addressing mode instead of a 64-bit VALU add per access
+  __device__ __forceinline__ double ldb(int id, unsigned qb) const {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(pl(id)) + qb);
+  }
+  __device__ __forceinline__ void stb(int id, unsigned qb, double v) const {
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(pl(id)) + qb) = v;
+  }
+  __device__ __forceinline__ void areab(int d, unsigned qb, double* a) const {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = ldb(PL_FA + 4 * d + c, qb);
+  }
 };
 
 struct SolverDev {   // scalar run-time parameters of agx_config
@@ -620,13 +633,15 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
     }
     __syncthreads();
     int cur = 0;
-    for (int k = k0; k < k1; ++k, q += s_k, cur ^= 1) {
+    unsigned qb = (unsigned)(q * 8);
+    const unsigned skb = (unsigned)(s_k * 8), sxb = (unsigned)(b.sx * 8);
+    for (int k = k0; k < k1; ++k, q += s_k, qb += skb, cur ^= 1) {
       const double* tc = &tile[cur][0][0][0];
       double* tn = &tile[cur ^ 1][0][0][0];
       // the load needed first is issued first (vmcnt retires in order), the
       // next-step prefetch after it
       double ak_up[4];
-      b.area(2, q + s_k, ak_up);
+      b.areab(2, qb + skb, ak_up);
       double nxt[AGX_NEQ], nwk, nwi, nwj;
       if AGX_AB(128) {
 #pragma unroll
@@ -634,10 +649,10 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         nwk = wk[0]; nwi = wk[0]; nwj = wk[0];
       } else {
 #pragma unroll
-        for (int e = 0; e < AGX_NEQ; ++e) nxt[e] = b.state(e)[q + (H + 1) * s_k];
-        nwk = b.wid(2)[q + (H + 1) * s_k];
-        nwi = b.wid(0)[q + s_k];
-        nwj = b.wid(1)[q + s_k];
+        for (int e = 0; e < AGX_NEQ; ++e) nxt[e] = b.ldb(b.st + e, qb + (H + 1) * skb);
+        nwk = b.ldb(PL_WID + 2, qb + (H + 1) * skb);
+        nwi = b.ldb(PL_WID + 0, qb + skb);
+        nwj = b.ldb(PL_WID + 1, qb + skb);
       }
       // InvCellSpectralRadius spectralRadius.hpp:44-64, one direction per block
       const double* sc = W[H - 1];
@@ -696,8 +711,8 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         double fi[AGX_NEQ] = {0, 0, 0, 0, 0};
         if (cell) {
           double l[AGX_NEQ], r[AGX_NEQ], ai_lo[4], ai_up[4];
-          b.area(0, q, ai_lo);
-          b.area(0, q + 1, ai_up);
+          b.areab(0, qb, ai_lo);
+          b.areab(0, qb + 8, ai_up);
           const double* base = tc + to;
           if AGX_AB(2) {
 #pragma unroll
@@ -731,13 +746,13 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
       // this evens the four SIMDs out at five flux evaluations each. ----
       if (cell && BAL && wv < 2) {
         double aj_lo[4], aj_up[4];
-        b.area(1, q, aj_lo);
-        b.area(1, q + b.sx, aj_up);
+        b.areab(1, qb, aj_lo);
+        b.areab(1, qb + sxb, aj_up);
         sr_j = AGX_AB(16) ? 1.0 : specrad(aj_lo, aj_up);
       } else if (cell) {
         double l[AGX_NEQ], r[AGX_NEQ], f[AGX_NEQ], aj_lo[4], aj_up[4];
-        b.area(1, q, aj_lo);
-        b.area(1, q + b.sx, aj_up);
+        b.areab(1, qb, aj_lo);
+        b.areab(1, qb + sxb, aj_up);
         const double* base = tc + to;
         if AGX_AB(2) {
 #pragma unroll
@@ -770,11 +785,11 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         tn[AGX_NEQ * PLANE + to] = nwi;
         tn[(AGX_NEQ + 1) * PLANE + to] = nwj;
       }
-      const double vol = b.pl(PL_VOL)[q];
+      const double vol = b.ldb(PL_VOL, qb);
       double cn[AGX_NEQ];
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e)
-        cn[e] = (FUSE == 1 && ma.mode != 0) ? b.pl(PL_CONSN + e)[q] : 0.0;
+        cn[e] = (FUSE == 1 && ma.mode != 0) ? b.ldb(PL_CONSN + e, qb) : 0.0;
       __syncthreads();
       if (cell) {
         if (BAL && wv < 2) {
@@ -793,10 +808,10 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         const bool st_ok = !AGX_AB(4) || res[0] == 12345.678;
         if (st_ok) {
 #pragma unroll
-          for (int e = 0; e < AGX_NEQ; ++e) b.pl(PL_RESID + e)[q] = res[e];
-          b.pl(PL_SPECRAD)[q] = sr;
-          if (sp.implicit) b.pl(PL_A)[q] = sr;
-          if (!sp.viscous) b.pl(PL_DT)[q] = dt;
+          for (int e = 0; e < AGX_NEQ; ++e) b.stb(PL_RESID + e, qb, res[e]);
+          b.stb(PL_SPECRAD, qb, sr);
+          if (sp.implicit) b.stb(PL_A, qb, sr);
+          if (!sp.viscous) b.stb(PL_DT, qb, dt);
         }
         if (FUSE) {
           double u[AGX_NEQ], ns[AGX_NEQ];
@@ -805,7 +820,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
             prim_to_cons(g, sc, u);            // U_n of this step
             if (FUSE == 2 && st_ok) {          // AssignSolToTimeN procBlock.cpp:1037
 #pragma unroll
-              for (int e = 0; e < AGX_NEQ; ++e) b.pl(PL_CONSN + e)[q] = u[e];
+              for (int e = 0; e < AGX_NEQ; ++e) b.stb(PL_CONSN + e, qb, u[e]);
             }
           } else {
 #pragma unroll
@@ -822,7 +837,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
           }
           if (st_ok) {
 #pragma unroll
-            for (int e = 0; e < AGX_NEQ; ++e) b.snew(e)[q] = ns[e];
+            for (int e = 0; e < AGX_NEQ; ++e) b.stb(b.sn + e, qb, ns[e]);
           }
           const long lin0 = (((long)k * b.nj + j) * b.ni + i) * AGX_NEQ;
           double vm = sNorm[AGX_NEQ][wv][lane];
@@ -894,21 +909,31 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
     }
     __syncthreads();
     int cur = 0;
-    for (int k = k0; k < k1; ++k, cur ^= 1) {
+    // byte offsets inside a plane, see SlabDev::ldb
+    const unsigned skb = (unsigned)(s_k * 8);
+    unsigned qrowb[H];
+#pragma unroll
+    for (int m = 0; m < H; ++m) qrowb[m] = (unsigned)((qrow[m] + (long)(k0 + 1) * s_k) * 8);
+    unsigned qcolb = (unsigned)((qcol + (long)(k0 + 1) * s_k) * 8);
+    unsigned qfb = (unsigned)((qf + (long)k0 * s_k) * 8);
+    unsigned qob = (unsigned)(b.idx(min(i0 + lane, b.ni - 1), min(j0 + (top ? 0 : 1), b.nj - 1), k0) * 8);
+    for (int k = k0; k < k1; ++k, cur ^= 1, qcolb += skb, qfb += skb, qob += skb) {
       const double* tc = &tile[cur][0][0][0];
       double* tn = &tile[cur ^ 1][0][0][0];
       double af[4] = {0, 0, 0, 1};
       if AGX_AB(32) { __syncthreads(); continue; }
-      if (do_f) b.area(top ? 1 : 0, qf + (long)k * s_k, af);
+      if (do_f) b.areab(top ? 1 : 0, qfb, af);
       // prefetch the halo ring of plane k+1
       double hv[NV][H], hcv[NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        const double* p = b.pl(v < AGX_NEQ ? b.st + v : PL_WID + (v - AGX_NEQ));
+        const int pid = v < AGX_NEQ ? b.st + v : PL_WID + (v - AGX_NEQ);
 #pragma unroll
-        for (int m = 0; m < H; ++m) hv[v][m] = p[qrow[m] + (long)(k + 1) * s_k];
-        hcv[v] = hc ? p[qcol + (long)(k + 1) * s_k] : 0.0;
+        for (int m = 0; m < H; ++m) hv[v][m] = b.ldb(pid, qrowb[m]);
+        hcv[v] = hc ? b.ldb(pid, qcolb) : 0.0;
       }
+#pragma unroll
+      for (int m = 0; m < H; ++m) qrowb[m] += skb;
       if (do_f) {
         double l[AGX_NEQ], r[AGX_NEQ], f[AGX_NEQ];
         const double* base = tc + fo;
@@ -933,7 +958,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         const int orow = top ? 0 : 1;
         if (i0 + lane < itop && j0 + orow < jtop) {
           double ao[4], l[AGX_NEQ], r[AGX_NEQ], f[AGX_NEQ];
-          b.area(1, b.idx(i0 + lane, j0 + orow, k), ao);
+          b.areab(1, qob, ao);
           const double* base = tc + (orow + H) * TW + lane + H;
           recon_generic<RECON, LIM>(
               [&](int e, int m) { return base[e * PLANE + m * TW]; },
