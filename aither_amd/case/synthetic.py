@@ -150,3 +150,36 @@ def stacked_blocks_case(n=(16, 16, 16), nblocks=2, axis="k", stretch=1.0,
     if amplitude:
         perturbed_state(case, amplitude)
     return case
+
+
+def cube_blocks_case(n=(8, 8, 8), splits=(2, 2, 2), bcs=None, amplitude=0.05,
+                     ranks=None, **deck_kw):
+    """splits[0] x splits[1] x splits[2] boxes of n cells each tiling one box
+    (BASELINE configs[3] style: 2x2x2 = 8 blocks), joined face to face by
+    interblock connections; block id = bi + si * (bj + sj * bk)."""
+    ni, nj, nk = n
+    si, sj, sk = splits
+    deck = make_deck(**deck_kw)
+    coords, all_bcs = [], []
+    bid = lambda a, b_, c: a + si * (b_ + sj * c)
+    for bk in range(sk):
+        for bj in range(sj):
+            for bi in range(si):
+                coords.append(box_nodes(ni, nj, nk, 1.0,
+                                        origin=(float(bi), float(bj), float(bk))))
+                blk = dict(bcs or {})
+                idx, cnt = (bi, bj, bk), (si, sj, sk)
+                for d in range(3):
+                    lo_s, hi_s = 2 * d + 1, 2 * d + 2
+                    if idx[d] > 0:
+                        nb = list(idx); nb[d] -= 1
+                        blk[lo_s] = ("interblock", 1000 * hi_s + bid(*nb))
+                    if idx[d] < cnt[d] - 1:
+                        nb = list(idx); nb[d] += 1
+                        blk[hi_s] = ("interblock", 1000 * lo_s + bid(*nb))
+                all_bcs.append(box_surfaces(ni, nj, nk, blk))
+    deck.bcs = all_bcs
+    case = _b.build_case(None, deck=deck, coords=coords, ranks=ranks)
+    if amplitude:
+        perturbed_state(case, amplitude)
+    return case
