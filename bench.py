@@ -43,9 +43,14 @@ BYTES_STAGE = 296          # explicit stage, nEq = 5
 BYTES_RESID_KERNEL = 216   # of which the residual kernel: state 5 + areas 12 +
                            # widths 3 + vol 1 read, residual 5 + dt 1 written
 BYTES_LUSGS_ITER = 1296    # scalar LU-SGS viscous iteration
+BYTES_DPLUR4_ITER = 1960   # inviscid DPLUR, 4 sweeps
 
 
 def deck_kwargs(workload):
+    if workload == "dplur8":
+        return dict(face_reconstruction="thirdOrder", limiter="vanAlbada",
+                    inviscid_flux="ausm", time_integration="implicitEuler",
+                    matrix_solver="dplur", matrix_sweeps=4, cfl=10.0)
     if workload == "rk4":
         return dict(time_integration="rk4", cfl=0.5,
                     face_reconstruction="thirdOrder", limiter="vanAlbada",
@@ -61,6 +66,12 @@ def rank_local_chain_case(rank, nranks, n, workload, dims=None):
     Only this rank's block is built at full size; its neighbours are built
     four cells thick, which is all the ghost-geometry exchange reads."""
     kw = deck_kwargs(workload)
+    if workload == "dplur8":
+        # BASELINE configs[3]: 2 x 2 x 2 blocks of (n/2)^3 cells, 8 / nranks per rank
+        case = synthetic.cube_blocks_case(n=(n // 2,) * 3, splits=(2, 2, 2),
+                                          ranks=[b * nranks // 8 for b in range(8)], **kw)
+        case.total_cells = 8 * (n // 2) ** 3
+        return case
     bcs = None
     if workload == "lusgs":
         bcs = {3: ("viscousWall", 2), 1: ("characteristic", 1),
@@ -155,7 +166,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workload", choices=["rk4", "lusgs"], default="rk4")
+    ap.add_argument("--workload", choices=["rk4", "lusgs", "dplur8"], default="rk4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dims", default=None,
                     help="ni,nj,nk of a non-cubic block (kernel experiments only)")
@@ -233,6 +244,9 @@ def main():
     if rank == 0:
         cells_rank = dims[0] * dims[1] * dims[2] if dims else n ** 3
         total_cells = cells_rank * world
+        if args.workload == "dplur8":      # strong scaling: the 8 blocks are divided
+            total_cells = 8 * (n // 2) ** 3
+            cells_rank = total_cells // world
         value = total_cells * args.steps / elapsed / 1e6
         t_res, n_res = group(0)
         t_upd, n_upd = group(1)
@@ -261,11 +275,14 @@ def main():
         else:
             dev_ms = (t_res * n_res + t_upd * n_upd + t_bc * n_bc +
                       t_swp * n_swp) / max(args.steps, 1)
-            achieved = BYTES_LUSGS_ITER * cells_rank / (dev_ms * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel="LU-SGS iteration (all kernels)",
+            bpc = BYTES_LUSGS_ITER if args.workload == "lusgs" else BYTES_DPLUR4_ITER
+            achieved = bpc * cells_rank / (dev_ms * 1e-3) / 1e9
+            roof = dict(bound="hbm",
+                        kernel=("LU-SGS" if args.workload == "lusgs" else "DPLUR") +
+                        " iteration (all kernels)",
                         achieved=achieved, peak=HBM_PEAK / 1e9, unit="GB/s",
                         frac=achieved * 1e9 / HBM_PEAK, traffic=None,
-                        bytes_per_cell=BYTES_LUSGS_ITER, avg_launch_ms=dev_ms,
+                        bytes_per_cell=bpc, avg_launch_ms=dev_ms,
                         sweep_ms=t_swp * n_swp / max(args.steps, 1))
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
@@ -283,17 +300,23 @@ def main():
             "value": value, "unit": "Mcell-updates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True,
+            "scaling": "strong" if args.workload == "dplur8" else "weak",
+            "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (
                 f"single {n}^3 block per GPU, single-species air, MUSCL "
                 "thirdOrder + vanAlbada + Roe, RK4 explicit, slip walls"
                 if args.workload == "rk4" else
                 f"single {n}^3 block per GPU, WENO5 + AUSMPW+ + viscous, "
-                "implicit Euler LU-SGS 1 sweep, viscous wall + characteristic"),
+                "implicit Euler LU-SGS 1 sweep, viscous wall + characteristic"
+                if args.workload == "lusgs" else
+                f"2x2x2 blocks of {n // 2}^3 cells shared by the GPUs, Euler MUSCL + "
+                "AUSMPW+, implicit Euler DPLUR 4 sweeps, slip walls"),
                 "iteration": "one mgSolution::Iterate call (one RK stage)"
                 if args.workload == "rk4" else "one nonlinear iteration",
-                "blocks": world, "cells_per_gpu": cells_rank,
+                "blocks": 8 if args.workload == "dplur8" else world,
+                "cells_per_gpu": cells_rank,
                 "halo": "RCCL p2p between phases" if world > 1 else "none"},
             "roofline": roof,
         }
