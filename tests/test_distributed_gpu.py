@@ -1,0 +1,100 @@
+"""The multi-rank path on a real GPU: two processes share cuda:0, each drives its
+own block through the HIP library with PhasedSolver, and the halo slabs that
+agx_halo_pack leaves in device buffers travel between the processes (staged
+through the host and gloo here; bench.py hands the same device buffers to RCCL).
+Checked against the single-process CPU oracle at 1e-10."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import _oracle_lib
+from parity_utils import rel_err, RTOL
+from aither_amd import abi
+from aither_amd.case import synthetic
+from aither_amd.solver import Solver, PhasedSolver
+
+KW = {
+    "rk4": dict(time_integration="rk4", cfl=0.5),
+    "dplur": dict(inviscid_flux="ausm", limiter="none", time_integration="implicitEuler",
+                  matrix_solver="dplur", matrix_sweeps=4, cfl=5.0),
+    "lusgs": dict(time_integration="implicitEuler", matrix_solver="lusgs", cfl=5.0),
+}
+DIMS = (70, 9, 8)
+
+
+def _case(kind, ranks):
+    return synthetic.stacked_blocks_case(DIMS, nblocks=2, axis="k", stretch=1.1,
+                                         ranks=ranks, **KW[kind])
+
+
+def _exchange(items):
+    """device slab -> host -> gloo -> host -> device"""
+    reqs, staged = [], []
+    for peer, tag, send, recv in items:
+        hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        staged.append((recv, hr))
+        reqs.append(dist.isend(hs, peer, tag=tag))
+        reqs.append(dist.irecv(hr, peer, tag=tag))
+    for r in reqs:
+        r.wait()
+    for recv, hr in staged:
+        recv.copy_(hr)
+    torch.cuda.synchronize()
+
+
+def _alloc(cnt):
+    return torch.empty(max(int(cnt), 1), dtype=torch.float64, device="cuda")
+
+
+def _worker(rank, port, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    import aither_amd
+    agx = aither_amd.load()
+    case = _case(kind, [0, 1])
+    sol = PhasedSolver(agx, case, rank, _exchange, _alloc)
+    for nn in range(2):
+        sol.step(nn)
+    (gb,) = sol.block_ids
+    q.put((rank, sol.download("state", gb), np.array([h["l2"] ** 2 for h in sol.history])))
+    dist.barrier()
+    sol.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", sorted(KW))
+def test_two_ranks_on_one_gpu(oracle, kind):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, st, l2 = q.get(timeout=300)
+        res[rank] = (st, l2)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    case = _case(kind, None)
+    ref = Solver(oracle, case)
+    for nn in range(2):
+        ref.step(nn)
+    ng = case.ng
+    core = lambda a: a[ng:-ng, ng:-ng, ng:-ng]
+    l2ref = np.array([h["l2"] ** 2 for h in ref.history])
+    assert rel_err((res[0][1] + res[1][1]), l2ref) < RTOL
+    for r in range(2):
+        assert rel_err(core(res[r][0]), core(ref.download("state", r))) < RTOL
+    ref.close()
