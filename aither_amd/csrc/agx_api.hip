@@ -531,7 +531,7 @@ int bc_pass(agx_ctx* c, bool faces, int viscous) {
         const int st = surface_type(s);
         const int d3 = (st - 1) / 2, d1 = (d3 + 1) % 3, d2 = (d3 + 2) % 3;
         const int lo[3] = {s.imin, s.jmin, s.kmin}, hi[3] = {s.imax, s.jmax, s.kmax};
-        nmax = std::max(nmax, (long)(hi[d1] - lo[d1]) * (hi[d2] - lo[d2]) * b.ng);
+        nmax = std::max(nmax, (long)(hi[d1] - lo[d1]) * (hi[d2] - lo[d2]));
       }
       if (nmax > 0)
         hipLaunchKernelGGL(k_bc_faces, dim3((nmax + 255) / 256, b.nsurf), dim3(256), 0,

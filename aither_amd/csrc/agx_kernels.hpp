@@ -1277,36 +1277,40 @@ __global__ void k_bc_faces(BlockDev b, GasDev g, int viscous, int* err) {
   const int lo[3] = {sf.imin, sf.jmin, sf.kmin}, hi[3] = {sf.imax, sf.jmax, sf.kmax};
   const int n1 = hi[d1] - lo[d1], n2 = hi[d2] - lo[d2];
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long)n1 * n2 * b.ng) return;
-  const int layer = (int)(t / ((long)n1 * n2)) + 1;
-  const int rem = (int)(t % ((long)n1 * n2));
+  if (t >= (long)n1 * n2) return;
+  int bc = sf.bc_type;
+  if (bc == AGX_BC_INTERBLOCK || bc == AGX_BC_PERIODIC) return;
+  if (viscous) { if (bc != AGX_BC_VISCOUSWALL) return; }
+  else if (bc == AGX_BC_VISCOUSWALL) bc = AGX_BC_SLIPWALL;
+  const int rem = (int)t;
   // the fastest-varying surface direction gets consecutive lanes
   int a1, a2;
   if (d1 < d2) { a1 = lo[d1] + rem % n1; a2 = lo[d2] + rem / n1; }
   else { a2 = lo[d2] + rem % n2; a1 = lo[d1] + rem / n2; }
   const int nn[3] = {b.ni, b.nj, b.nk};
   const int r3 = lo[d3];
-  int gCell, iCell, aCell;
-  if (st % 2 == 0) {
-    gCell = r3 + layer - 1; iCell = max(r3 - layer, 0); aCell = r3 - 1;
-  } else {
-    gCell = r3 - layer; iCell = min(r3 + layer - 1, nn[d3] - 1); aCell = r3;
-  }
-  int bc = sf.bc_type;
-  if (bc == AGX_BC_INTERBLOCK || bc == AGX_BC_PERIODIC) return;
-  if (viscous) { if (bc != AGX_BC_VISCOUSWALL) return; }
-  else if (bc == AGX_BC_VISCOUSWALL) bc = AGX_BC_SLIPWALL;
-  const int src = (bc == AGX_BC_SLIPWALL || viscous) ? iCell : aCell;
   int c[3];
   c[d1] = a1; c[d2] = a2;
-  c[d3] = src;   const long qs = b.idx(c[0], c[1], c[2]);
-  c[d3] = gCell; const long qg = b.idx(c[0], c[1], c[2]);
-  c[d3] = r3;    const long qf = b.idx(c[0], c[1], c[2]);
-  double in[AGX_NEQ], gh[AGX_NEQ], area[4];
-  load5(b.state, qs, in);
-  load_area(b, d3, qf, area);
-  if (!ghost_state(g, in, bc, area, st, sf.state, layer, gh)) { *err = 1; return; }
-  store5(b.state, qg, gh);
+  c[d3] = r3;
+  double area[4];
+  load_area(b, d3, b.idx(c[0], c[1], c[2]), area);
+  // one thread fills all ghost layers of its surface cell: on i-surfaces the
+  // layers (and the interior cells they mirror) share cache lines
+  for (int layer = 1; layer <= b.ng; ++layer) {
+    int gCell, iCell, aCell;
+    if (st % 2 == 0) {
+      gCell = r3 + layer - 1; iCell = max(r3 - layer, 0); aCell = r3 - 1;
+    } else {
+      gCell = r3 - layer; iCell = min(r3 + layer - 1, nn[d3] - 1); aCell = r3;
+    }
+    const int src = (bc == AGX_BC_SLIPWALL || viscous) ? iCell : aCell;
+    c[d3] = src;   const long qs = b.idx(c[0], c[1], c[2]);
+    c[d3] = gCell; const long qg = b.idx(c[0], c[1], c[2]);
+    double in[AGX_NEQ], gh[AGX_NEQ];
+    load5(b.state, qs, in);
+    if (!ghost_state(g, in, bc, area, st, sf.state, layer, gh)) { *err = 1; return; }
+    store5(b.state, qg, gh);
+  }
 }
 
 // Edge ghost cells: procBlock::AssignInviscidGhostCellsEdge procBlock.cpp:2565-2708
