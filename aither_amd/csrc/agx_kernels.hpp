@@ -1845,11 +1845,24 @@ __device__ __forceinline__ void lusgs_fetch_dir(const BlockDev& b, const SolverD
 template <bool FORWARD>
 __device__ __forceinline__ void lusgs_fetch(const BlockDev& b, const SolverDev& sp,
                                             int i0, int bi, int li, int lj, int lk, int j,
-                                            int k, LusgsCell& c) {
+                                            int k, int full, LusgsCell& c) {
   const int i = i0 + li;
   const long q = b.idx(i, j, k);
   double t[LREC];
-  lusgs_ld(b.rec_dyn + q * LREC, 0, 8, t);
+  // a lone wave pays ~200 cycles per scattered 16-byte-per-lane load, so only
+  // the part of the record this half sweep uses is read: {1/A, state, b} going
+  // forward, {x, 1/A, state} going back (everything when both triangles count)
+  if (full) {
+    lusgs_ld(b.rec_dyn + q * LREC, 0, 8, t);
+  } else if (FORWARD) {
+    lusgs_ld(b.rec_dyn + q * LREC, 4, 6, t + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = 0.0;
+  } else {
+    lusgs_ld(b.rec_dyn + q * LREC, 0, 6, t);
+#pragma unroll
+    for (int e = 12; e < LREC; ++e) t[e] = 0.0;
+  }
 #pragma unroll
   for (int e = 0; e < AGX_NEQ; ++e) { c.x[e] = t[e]; c.s[e] = t[6 + e]; c.rb[e] = t[11 + e]; }
   c.ainv = t[5];
@@ -1916,12 +1929,12 @@ __device__ __forceinline__ void lusgs_brick_body(const BlockDev& b, const GasDev
   }
   // two cell buffers used alternately: one is consumed while the other is filled
   LusgsCell ca, cb;
-  if (act_at(0)) lusgs_fetch<FORWARD>(b, sp, i0, bi, li_at(0), lj, lk, j, k, ca);
+  if (act_at(0)) lusgs_fetch<FORWARD>(b, sp, i0, bi, li_at(0), lj, lk, j, k, full, ca);
   auto step = [&](int t, const LusgsCell& cur, LusgsCell& nxt) {
     const int li = li_at(t);
     const bool act = act_at(t);
     if (t + 1 < nsteps && act_at(t + 1))
-      lusgs_fetch<FORWARD>(b, sp, i0, bi, li_at(t + 1), lj, lk, j, k, nxt);
+      lusgs_fetch<FORWARD>(b, sp, i0, bi, li_at(t + 1), lj, lk, j, k, full, nxt);
     // what the neighbouring lanes finished in the previous step
     double jx[AGX_NEQ], js[AGX_NEQ], jc[3], ja[4], kx[AGX_NEQ], ks[AGX_NEQ], kc[3], ka[4];
 #pragma unroll
