@@ -81,6 +81,7 @@ def make_deck(**kw):
         State("pressureOutlet", dict(tag=3, pressure=101325.0)),
         State("viscousWall", dict(tag=4, temperature=300.0,
                                   velocity=[5.0, 0.0, 0.0])),
+        State("viscousWall", dict(tag=5, heatFlux=2.0e3)),
     ]
     return d
 

@@ -297,7 +297,7 @@ int check_device_error(agx_ctx* c) {
       return fail("LU-SGS pipeline: a brick waited beyond the spin limit for its "
                   "predecessors (AGX_LUSGS=brick selects the launch-per-plane form)");
     return fail("a boundary-condition variant outside this build's coverage "
-                "was requested (nonreflecting inlet/outlet or heat-flux wall)");
+                "was requested (nonreflecting inlet/outlet)");
   }
   return 0;
 }
@@ -727,7 +727,7 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
   HIPCHK(hipMemsetAsync(b.slab, 0, sizeof(double) * d.nplane * PL_COUNT, c->stream));
   auto pl = [&](int id) { return b.slab + (long)id * d.nplane; };
   d.vol = pl(PL_VOL); d.specrad = pl(PL_SPECRAD); d.dt = pl(PL_DT);
-  d.a = pl(PL_A); d.ainv = pl(PL_AINV);
+  d.a = pl(PL_A); d.ainv = pl(PL_AINV); d.wdist = pl(PL_WDIST);
   for (int e = 0; e < AGX_NEQ; ++e) {
     d.state[e] = pl(PL_STATE_A + e); d.state2[e] = pl(PL_STATE_B + e);
     d.resid[e] = pl(PL_RESID + e); d.consn[e] = pl(PL_CONSN + e);
@@ -762,6 +762,10 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
   if (d.rec_geo)
     hipLaunchKernelGGL(k_lusgs_geo, dim3((d.nplane + 255) / 256), dim3(256), 0, c->stream, d);
   HIPCHK(hipGetLastError());
+  if (g->wall_dist) {
+    double* wp[1] = {d.wdist};
+    if (upload_aos(c, b, g->wall_dist, wp, 1, ci, cj, ck, d.ng)) return 1;
+  }
   *block_id = (int)c->blocks.size() - 1;
   return 0;
 }

@@ -465,7 +465,7 @@ __device__ __forceinline__ void extrap_hold(const double* bnd, double factor,
 __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
                                    const double* area_unit, int surf,
                                    const agx_bc_state& d, int layer,
-                                   double* gh) {
+                                   double wall_dist, double* gh) {
 #pragma unroll
   for (int e = 0; e < AGX_NEQ; ++e) gh[e] = in[e];
   const double sgn = (surf % 2 == 1) ? -1.0 : 1.0;
@@ -482,7 +482,11 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
         const double tg = 2.0 * d.wall_temperature - temperature(g, in);
         gh[0] = gh[4] / (g.R * tg);
       } else if (d.is_heat_flux) {
-        return false;
+        // low-Re constant heat flux wall, ghostStates.cpp:228-242: the gradient
+        // length is twice the wall distance of the wall-adjacent cell
+        const double t = temperature(g, in);
+        const double tg = t - d.wall_heat_flux / conductivity(g, t) * 2.0 * wall_dist;
+        gh[0] = gh[4] / (g.R * tg);
       }
       return true;
     }

@@ -35,6 +35,7 @@ struct BlockDev {
   double* xold[AGX_NEQ];      // dplur copy              linearSolver.cpp:487
   double* a;                  // linearSolver::a_ (scalar flow part)
   double* ainv;               // linearSolver::aInv_
+  double* wdist;              // wallDist_                procBlock.hpp:88
   double* rec_dyn;            // LU-SGS sweep records, 16 doubles per cell (below)
   double* rec_geo;
   const agx_bc_surface* surf; // boundaryConditions      boundaryConditions.hpp:231
@@ -54,7 +55,8 @@ struct NormPartial { double l2[AGX_NEQ]; double vmax; long long lin; };
 enum {
   PL_STATE_A = 0, PL_STATE_B = 5, PL_RESID = 10, PL_CONSN = 15, PL_CONSNM1 = 20,
   PL_X = 25, PL_XOLD = 30, PL_FA = 35 /* + 4*d + c */, PL_VOL = 47, PL_CEN = 48,
-  PL_WID = 51, PL_SPECRAD = 54, PL_DT = 55, PL_A = 56, PL_AINV = 57, PL_COUNT = 58
+  PL_WID = 51, PL_SPECRAD = 54, PL_DT = 55, PL_A = 56, PL_AINV = 57, PL_WDIST = 58,
+  PL_COUNT = 59
 };
 struct SlabDev {               // compact view used by the marching kernel
   double* base;
@@ -1294,6 +1296,13 @@ __global__ void k_bc_faces(BlockDev b, GasDev g, int viscous, int* err) {
   c[d3] = r3;
   double area[4];
   load_area(b, d3, b.idx(c[0], c[1], c[2]), area);
+  // wall distance of the wall-adjacent cell (procBlock.cpp:2813), heat-flux walls only
+  double wd = 0.0;
+  if (bc == AGX_BC_VISCOUSWALL && sf.state.is_heat_flux) {
+    c[d3] = st % 2 == 0 ? r3 - 1 : r3;
+    wd = b.wdist[b.idx(c[0], c[1], c[2])];
+    c[d3] = r3;
+  }
   // one thread fills all ghost layers of its surface cell: on i-surfaces the
   // layers (and the interior cells they mirror) share cache lines
   for (int layer = 1; layer <= b.ng; ++layer) {
@@ -1308,7 +1317,7 @@ __global__ void k_bc_faces(BlockDev b, GasDev g, int viscous, int* err) {
     c[d3] = gCell; const long qg = b.idx(c[0], c[1], c[2]);
     double in[AGX_NEQ], gh[AGX_NEQ];
     load5(b.state, qs, in);
-    if (!ghost_state(g, in, bc, area, st, sf.state, layer, gh)) { *err = 1; return; }
+    if (!ghost_state(g, in, bc, area, st, sf.state, layer, wd, gh)) { *err = 1; return; }
     store5(b.state, qg, gh);
   }
 }
@@ -1356,13 +1365,13 @@ __global__ void k_bc_edges(BlockDev b, GasDev g, int viscous, int* err) {
         c[e2] = cF22; c[e3] = g3;
         load_area(b, e2, b.idx(c[0], c[1], c[2]), area);
         load5(b.state, qP2, in);
-        if (!ghost_state(g, in, bc2, area, surf2, s2->state, layer2, gh)) { *err = 1; return; }
+        if (!ghost_state(g, in, bc2, area, surf2, s2->state, layer2, 0.0, gh)) { *err = 1; return; }
         store5(b.state, qG, gh);
       } else if (bc2 != AGX_BC_SLIPWALL && bc3 == AGX_BC_SLIPWALL) {
         c[e2] = g2; c[e3] = cF33;
         load_area(b, e3, b.idx(c[0], c[1], c[2]), area);
         load5(b.state, qP3, in);
-        if (!ghost_state(g, in, bc3, area, surf3, s3->state, layer3, gh)) { *err = 1; return; }
+        if (!ghost_state(g, in, bc3, area, surf3, s3->state, layer3, 0.0, gh)) { *err = 1; return; }
         store5(b.state, qG, gh);
       } else if (!viscous || (bc2 == AGX_BC_VISCOUSWALL && bc3 == AGX_BC_VISCOUSWALL)) {
         if (layer2 == layer3) {

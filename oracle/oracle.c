@@ -568,7 +568,8 @@ static void extrap_hold(const double *bnd, double factor, const double *in,
  * inlet/outlet) */
 static int ghost_state(const ora_ctx *c, const double *interior, int bc,
                        const double *areaVec, int surf,
-                       const agx_bc_state *d, int layer, double *ghost) {
+                       const agx_bc_state *d, int layer, double wallDist,
+                       double *ghost) {
   for (int e = 0; e < NEQ; ++e) ghost[e] = interior[e];
   const int isLower = surf % 2 == 1;
   double n[3];
@@ -587,9 +588,13 @@ static int ghost_state(const ora_ctx *c, const double *interior, int bc,
       const double rho = ghost[4] / (R * tGhost);
       ghost[0] = rho * (interior[0] / interior[0]);
     } else if (d->is_heat_flux) {
-      /* ghostStates.cpp:222-235; 2x wall distance handled by caller through
-       * length_scale is not available here -> not supported */
-      return fail("constant heat flux wall needs wall distance: unsupported");
+      /* low-Re constant heat flux wall, ghostStates.cpp:228-242 */
+      const double t = temperature(c, interior);
+      const double kappa = conductivity(c, t);
+      const double tGhost = t - d->wall_heat_flux / kappa * 2.0 * wallDist;
+      const double R = 0.0 + 1.0 * c->cfg.gas.gas_constant;
+      const double rho = ghost[4] / (R * tGhost);
+      ghost[0] = rho * (interior[0] / interior[0]);
     }
   } else if (bc == AGX_BC_CHARACTERISTIC) {
     double fs[NEQ] = {d->density * 1.0, d->velocity[0], d->velocity[1],
@@ -788,8 +793,10 @@ static int assign_ghost_faces(ora_ctx *c, blk_t *b, int viscous) {
           surf_ijk(d3, bnd, a1, a2, &fi, &fj, &fk);
           const double *area = b->fa[d3] + 4 * FI(b, d3, fi, fj, fk);
           double g[NEQ];
+          int wi, wj, wk;                    /* procBlock.cpp:2813: aCell */
+          surf_ijk(d3, aCell, a1, a2, &wi, &wj, &wk);
           if (ghost_state(c, b->state + NEQ * CI(b, i, j, k), bc, area, st,
-                          &q->state, layer, g))
+                          &q->state, layer, b->wdist ? b->wdist[CI(b, wi, wj, wk)] : 0.0, g))
             return 1;
           memcpy(b->state + NEQ * CI(b, gi, gj, gk), g, sizeof g);
         }
@@ -853,11 +860,11 @@ static int assign_ghost_edges(ora_ctx *c, blk_t *b, int viscous) {
 #undef PERM
             double g[NEQ];
             if (bc2 == AGX_BC_SLIPWALL && bc3 != AGX_BC_SLIPWALL) {
-              if (ghost_state(c, sP2, bc2, fArea2, surf2, &s2->state, layer2, g))
+              if (ghost_state(c, sP2, bc2, fArea2, surf2, &s2->state, layer2, 0.0, g))
                 return 1;
               memcpy(sG, g, sizeof g);
             } else if (bc2 != AGX_BC_SLIPWALL && bc3 == AGX_BC_SLIPWALL) {
-              if (ghost_state(c, sP3, bc3, fArea3, surf3, &s3->state, layer3, g))
+              if (ghost_state(c, sP3, bc3, fArea3, surf3, &s3->state, layer3, 0.0, g))
                 return 1;
               memcpy(sG, g, sizeof g);
             } else if (!viscous || (bc2 == AGX_BC_VISCOUSWALL &&

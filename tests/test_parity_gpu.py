@@ -164,6 +164,8 @@ SLIP = None
 FARFIELD = {s: ("characteristic", 1) for s in range(1, 7)}
 WALL_J = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("pressureOutlet", 3),
           4: ("characteristic", 1)}
+WALL_HEATFLUX = {3: ("viscousWall", 5), 1: ("characteristic", 1), 2: ("pressureOutlet", 3),
+                 4: ("characteristic", 1)}
 WALL_ISO = {3: ("viscousWall", 4), 4: ("viscousWall", 2),
             1: ("characteristic", 1), 2: ("characteristic", 1)}
 
@@ -197,6 +199,11 @@ CASES = {
     "visc_explicit_rk4": dict(
         n=(9, 10, 8), stretch=1.2, bcs=WALL_J, equation_set="navierStokes",
         time_integration="rk4", cfl=0.3),
+    # constant-heat-flux wall (ghostStates.cpp:228-242): no reference truth holds
+    # this branch, so it is HIP-vs-oracle parity only
+    "visc_heatflux_wall_lusgs": dict(
+        n=(10, 9, 8), stretch=1.15, bcs=WALL_HEATFLUX, equation_set="navierStokes",
+        time_integration="implicitEuler", matrix_solver="lusgs", cfl=10.0),
 }
 
 
