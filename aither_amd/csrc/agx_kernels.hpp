@@ -1833,7 +1833,7 @@ struct LusgsCell {
 
 // direction D of lusgs_fetch (a template so that every struct member is
 // addressed with a compile-time index and stays in registers)
-template <bool FORWARD, int D>
+template <bool FORWARD, int D, bool PIPE = false>
 __device__ __forceinline__ void lusgs_fetch_dir(const BlockDev& b, const SolverDev& sp,
                                                 long q, int i, int j, int k, int lcd,
                                                 int lextd, LusgsCell& c) {
@@ -1847,11 +1847,21 @@ __device__ __forceinline__ void lusgs_fetch_dir(const BlockDev& b, const SolverD
                   bc_is_connection(b, i + (D == 0), j + (D == 1), k + (D == 2), 2 * D + 2)));
   if (inside) c.inside |= 1 << D;
   if (use) c.use |= 1 << D;
-  if (use && !inside)
-    lusgs_load_nbr<FORWARD>(b, sp.viscous, q + (FORWARD ? -strd : strd), D, c.ob[D]);
+  if (use && !inside) {
+    const long qn = q + (FORWARD ? -strd : strd);
+    lusgs_load_nbr<FORWARD>(b, sp.viscous, qn, D, c.ob[D]);
+    if (PIPE) {
+      // the neighbouring brick wrote this x earlier in the SAME launch (possibly
+      // on another XCD): read it with agent-scope loads, after the progress check
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e)
+        c.ob[D].x[e] = __hip_atomic_load(b.rec_dyn + qn * LREC + e, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
-template <bool FORWARD>
+template <bool FORWARD, bool PIPE = false>
 __device__ __forceinline__ void lusgs_fetch(const BlockDev& b, const SolverDev& sp,
                                             int i0, int bi, int li, int lj, int lk, int j,
                                             int k, int full, LusgsCell& c) {
@@ -1883,9 +1893,9 @@ __device__ __forceinline__ void lusgs_fetch(const BlockDev& b, const SolverDev& 
     c.area[0][m] = t[3 + m]; c.area[1][m] = t[7 + m]; c.area[2][m] = t[11 + m];
   }
   c.use = 0; c.inside = 0;
-  lusgs_fetch_dir<FORWARD, 0>(b, sp, q, i, j, k, li, bi, c);
-  lusgs_fetch_dir<FORWARD, 1>(b, sp, q, i, j, k, lj, 8, c);
-  lusgs_fetch_dir<FORWARD, 2>(b, sp, q, i, j, k, lk, 8, c);
+  lusgs_fetch_dir<FORWARD, 0, PIPE>(b, sp, q, i, j, k, li, bi, c);
+  lusgs_fetch_dir<FORWARD, 1, PIPE>(b, sp, q, i, j, k, lj, 8, c);
+  lusgs_fetch_dir<FORWARD, 2, PIPE>(b, sp, q, i, j, k, lk, 8, c);
 }
 
 // the triangle opposite to the sweep direction (matrixSweeps > 1 only), values
@@ -1912,11 +1922,25 @@ __device__ __forceinline__ void lusgs_other_dir(const BlockDev& b, const GasDev&
                  !FORWARD ? 1.0 : -1.0, true, acc);
 }
 
+// Per-step hand-off between bricks of one launch (k_lusgs_pipe): flags[brick] =
+// epoch * 256 + number of fine steps whose x is visible.  A successor brick needs
+// the face cells of its predecessor eight steps after the predecessor formed
+// them, so it can run eight steps behind instead of a whole brick behind.
+struct LusgsStepSync {
+  int* flags;
+  int* err;
+  int epoch, spin_limit;
+  int self;            // own brick id
+  int pre[3];          // predecessor brick ids on the sweep side, -1: none
+  int nsp[3];          // their number of fine steps
+};
+
 // one brick, one wave
-template <bool FORWARD, int LBI>
-__device__ __forceinline__ void lusgs_brick_body(const BlockDev& b, const GasDev& g,
+template <bool FORWARD, int LBI, bool PIPE = false>
+__device__ __forceinline__ bool lusgs_brick_body(const BlockDev& b, const GasDev& g,
                                                  const SolverDev& sp, int full, int BI,
-                                                 int BJ, int BK) {
+                                                 int BJ, int BK,
+                                                 const LusgsStepSync* ss = nullptr) {
   const int lane = threadIdx.x;
   const int lj = lane & 7, lk = lane >> 3;
   const int i0 = BI * LBI, j = BJ * 8 + lj, k = BK * 8 + lk;
@@ -1937,13 +1961,62 @@ __device__ __forceinline__ void lusgs_brick_body(const BlockDev& b, const GasDev
     for (int m = 0; m < 4; ++m) prev.area[d][m] = 0.0;
   }
   // two cell buffers used alternately: one is consumed while the other is filled
+  // PIPE: the steps of the predecessors this brick's step t depends on
+  bool ok = true;
+  int pg[3] = {0, 0, 0};           // last progress value seen per predecessor
+  auto need = [&](int d, int t) {
+    // forward: the predecessor (always a full brick) forms the needed face cell
+    // ext steps after the step index this brick uses it at; backward the same
+    // counted from the other end of both step ranges
+    const int ext = d == 0 ? LBI : 8;
+    const int v = t + ext + (FORWARD ? 0 : ss->nsp[d] - nsteps);
+    return ss->epoch * 256 + max(0, min(v, ss->nsp[d]));
+  };
+  auto poll = [&](int d) {
+    return __hip_atomic_load(ss->flags + ss->pre[d], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto wait_for = [&](int t) {      // until every predecessor covers step t
+    if (!PIPE || t >= nsteps) return;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (ss->pre[d] < 0 || !ok) continue;
+      int spins = 0;
+      while (pg[d] < need(d, t)) {
+        pg[d] = poll(d);
+        if (pg[d] >= need(d, t)) break;
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > ss->spin_limit ||
+            __hip_atomic_load(ss->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          ok = false;
+          break;
+        }
+      }
+    }
+  };
+  auto publish = [&](int done) {    // steps 0 .. done-1 of this brick are visible
+    if (!PIPE) return;
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the x stores have landed
+    __hip_atomic_store(ss->flags + ss->self, ss->epoch * 256 + done, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  };
   LusgsCell ca, cb;
-  if (act_at(0)) lusgs_fetch<FORWARD>(b, sp, i0, bi, li_at(0), lj, lk, j, k, full, ca);
+  wait_for(0);
+  if (!ok) return false;
+  if (act_at(0)) lusgs_fetch<FORWARD, PIPE>(b, sp, i0, bi, li_at(0), lj, lk, j, k, full, ca);
   auto step = [&](int t, const LusgsCell& cur, LusgsCell& nxt) {
     const int li = li_at(t);
     const bool act = act_at(t);
+    if (PIPE) {
+      wait_for(t + 1);
+      if (!ok) return;
+      // refresh the progress values early for the step after next
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if (ss->pre[d] >= 0) pg[d] = poll(d);
+    }
     if (t + 1 < nsteps && act_at(t + 1))
-      lusgs_fetch<FORWARD>(b, sp, i0, bi, li_at(t + 1), lj, lk, j, k, full, nxt);
+      lusgs_fetch<FORWARD, PIPE>(b, sp, i0, bi, li_at(t + 1), lj, lk, j, k, full, nxt);
     // what the neighbouring lanes finished in the previous step
     double jx[AGX_NEQ], js[AGX_NEQ], jc[3], ja[4], kx[AGX_NEQ], ks[AGX_NEQ], kc[3], ka[4];
 #pragma unroll
@@ -1970,9 +2043,10 @@ __device__ __forceinline__ void lusgs_brick_body(const BlockDev& b, const GasDev
         ka[m] = __shfl_down(prev.area[2][m], 8, 64);
       }
     }
-    if (!act) return;
     const int i = i0 + li;
-    const long q = b.idx(i, j, k);
+    const long q = b.idx(i0 + max(0, min(li, bi - 1)), min(j, b.nj - 1), min(k, b.nk - 1));
+    double xn[AGX_NEQ] = {0, 0, 0, 0, 0};
+    if (act) {
     double acc[AGX_NEQ] = {0, 0, 0, 0, 0};
     const double sgn = FORWARD ? 1.0 : -1.0;
     // sweep side (L for the forward sweep, U for the backward sweep); the face
@@ -2025,7 +2099,6 @@ __device__ __forceinline__ void lusgs_brick_body(const BlockDev& b, const GasDev
       lusgs_nbr_term(g, sp, nx, ns, nc, in ? kmu : cur.ob[2].mu, na, cur.c, FORWARD, sgn,
                      cur.use & 4, acc);
     }
-    double xn[AGX_NEQ];
     if (full || FORWARD) {
       if (full) {
         lusgs_other_dir<FORWARD, 0>(b, g, sp, q, i, j, k, cur.area[0], cur.c, acc);
@@ -2038,10 +2111,22 @@ __device__ __forceinline__ void lusgs_brick_body(const BlockDev& b, const GasDev
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e) xn[e] = cur.x[e] + acc[e] * cur.ainv;
     }
+    }
+    // progress is published one step late, between the arithmetic of this step
+    // and its stores: the stores of step t-1 are a whole step old by now and the
+    // prefetch issued at the top of this step has had the arithmetic to land
+    if (PIPE) publish(t);
+    if (!act) return;
     double* r = b.rec_dyn + q * LREC;
-    reinterpret_cast<double2*>(r)[0] = make_double2(xn[0], xn[1]);
-    reinterpret_cast<double2*>(r)[1] = make_double2(xn[2], xn[3]);
-    r[4] = xn[4];
+    if (PIPE) {
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e)
+        __hip_atomic_store(r + e, xn[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      reinterpret_cast<double2*>(r)[0] = make_double2(xn[0], xn[1]);
+      reinterpret_cast<double2*>(r)[1] = make_double2(xn[2], xn[3]);
+      r[4] = xn[4];
+    }
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) { prev.x[e] = xn[e]; prev.s[e] = cur.s[e]; }
     prev.mu = cur.mu;
@@ -2054,8 +2139,14 @@ __device__ __forceinline__ void lusgs_brick_body(const BlockDev& b, const GasDev
   };
   for (int t = 0; t < nsteps; t += 2) {
     step(t, ca, cb);
-    if (t + 1 < nsteps) step(t + 1, cb, ca);
+    if (!ok) return false;
+    if (t + 1 < nsteps) {
+      step(t + 1, cb, ca);
+      if (!ok) return false;
+    }
   }
+  publish(nsteps);
+  return true;
 }
 
 // (a) one launch per coarse hyperplane (default): every wave takes the brick
@@ -2084,8 +2175,9 @@ k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi,
 //     smallest unfinished ticket never waits -- no dependence on dispatch order.
 //     Every wave leaves the loop when the tickets run out; a wave that spins
 //     longer than `spin_limit` polls raises *err and all waves drain.
-//     Visibility across CUs / XCDs: agent-scope release fence before the flag
-//     store, agent-scope acquire fence after the flag loads.
+//     Hand-off is per fine STEP (LusgsStepSync): x is stored with agent-scope
+//     (write-through) stores, the brick's progress counter follows after
+//     vmcnt(0), and consumers read counter and x with agent-scope loads.
 struct LusgsPipe {
   const int* order;     // ticket -> packed brick id (BI + nbi * (BJ + nbj * BK))
   int* flags;           // per brick: epoch of the half sweep that completed it
@@ -2108,35 +2200,25 @@ k_lusgs_pipe(BlockDev b, GasDev g, SolverDev sp, int full, int nbi, int nbj, int
     int id = pp.order[FORWARD ? t : pp.total - 1 - t];
     id = __builtin_amdgcn_readfirstlane(id);
     const int BI = id % nbi, BJ = (id / nbi) % nbj, BK = id / (nbi * nbj);
-    // predecessors on the sweep side
+    // predecessors on the sweep side and how many fine steps each of them has
     const int sd = FORWARD ? -1 : 1;
-    const int pi = BI + sd, pj = BJ + sd, pk = BK + sd;
-    const int pre[3] = {(pi >= 0 && pi < nbi) ? pi + nbi * (BJ + nbj * BK) : -1,
-                        (pj >= 0 && pj < nbj) ? BI + nbi * (pj + nbj * BK) : -1,
-                        (pk >= 0 && pk < nbk) ? BI + nbi * (BJ + nbj * pk) : -1};
-    bool ok = true;
+    const int pc[3][3] = {{BI + sd, BJ, BK}, {BI, BJ + sd, BK}, {BI, BJ, BK + sd}};
+    const int nb3[3] = {nbi, nbj, nbk};
+    LusgsStepSync ss;
+    ss.flags = pp.flags; ss.err = pp.err; ss.epoch = pp.epoch; ss.spin_limit = pp.spin_limit;
+    ss.self = id;
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      if (pre[m] < 0 || !ok) continue;
-      int spins = 0;
-      while (__hip_atomic_load(pp.flags + pre[m], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT) != pp.epoch) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > pp.spin_limit ||
-            __hip_atomic_load(pp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          ok = false;
-          break;
-        }
-      }
+    for (int d = 0; d < 3; ++d) {
+      const bool ex = pc[d][d] >= 0 && pc[d][d] < nb3[d];
+      ss.pre[d] = ex ? pc[d][0] + nbi * (pc[d][1] + nbj * pc[d][2]) : -1;
+      ss.nsp[d] = ex ? min(LBI, b.ni - pc[d][0] * LBI) + min(8, b.nj - pc[d][1] * 8) +
+                           min(8, b.nk - pc[d][2] * 8) - 2
+                     : 0;
     }
-    if (!ok) {
+    if (!lusgs_brick_body<FORWARD, LBI, true>(b, g, sp, full, BI, BJ, BK, &ss)) {
       __hip_atomic_store(pp.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    lusgs_brick_body<FORWARD, LBI>(b, g, sp, full, BI, BJ, BK);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_store(pp.flags + id, pp.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
