@@ -85,7 +85,7 @@ struct agx_ctx {
   bool use_tile = true;      // AGX_KERNEL=tile (default) | march
   int num_cu = 256;          // persistent workgroups of the tile kernel
   bool visc_gather = false;  // AGX_VISC=gather: one-thread-per-cell viscous kernel
-  int lusgs_mode = 1;        // AGX_LUSGS=plane (0) | brick (1, default) | pipe (2)
+  int lusgs_mode = 2;        // AGX_LUSGS=plane (0) | brick (1) | pipe (2, default)
   int lusgs_lbi = 8;         // brick length along i (AGX_LBI=8|16)
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
@@ -637,7 +637,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_WORKGROUPS")) c->num_cu = std::max(1, atoi(w));
     if (const char* w = getenv("AGX_VISC")) c->visc_gather = !strcmp(w, "gather");
     if (const char* w = getenv("AGX_LUSGS"))
-      c->lusgs_mode = !strcmp(w, "plane") ? 0 : (!strcmp(w, "pipe") ? 2 : 1);
+      c->lusgs_mode = !strcmp(w, "plane") ? 0 : (!strcmp(w, "brick") ? 1 : 2);
     if (const char* w = getenv("AGX_LBI")) c->lusgs_lbi = atoi(w) == 16 ? 16 : 8;
   }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));

@@ -2149,8 +2149,8 @@ __device__ __forceinline__ bool lusgs_brick_body(const BlockDev& b, const GasDev
   return true;
 }
 
-// (a) one launch per coarse hyperplane (default): every wave takes the brick
-//     (BJ, BK) of plane `cplane`
+// (a) one launch per coarse hyperplane (AGX_LUSGS=brick): every wave takes the
+//     brick (BJ, BK) of plane `cplane`
 template <bool FORWARD, int LBI>
 __global__ void __launch_bounds__(256)
 k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi, int nbj,
@@ -2163,13 +2163,11 @@ k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi,
   lusgs_brick_body<FORWARD, LBI>(b, g, sp, full, BI, BJ, BK);
 }
 
-// (b) ONE launch per half sweep (AGX_LUSGS=pipe): persistent waves draw bricks
-//     from a ticket counter in coarse-plane order and start a brick as soon as
-//     its three predecessor bricks have published their `done` flag, so the
-//     bricks of successive coarse planes overlap instead of waiting for a whole
-//     plane.  Measured 10 % faster than (a) at 256^3 (the chain of 94 dependent
-//     bricks stays the critical path either way), so (a), which needs no
-//     inter-workgroup protocol, is the default.
+// (b) ONE launch per half sweep (default): persistent waves draw bricks from a
+//     ticket counter in coarse-plane order; a brick publishes after every fine
+//     step how far it is, and a successor only needs its predecessors to be eight
+//     steps ahead (LusgsStepSync), so the dependent chain is the 766 fine
+//     hyperplanes of the block again instead of 94 bricks x 22 steps.
 //     Progress: a ticket is only ever held by a running wave and every
 //     predecessor of a brick has a smaller ticket, so the wave holding the
 //     smallest unfinished ticket never waits -- no dependence on dispatch order.
