@@ -84,12 +84,18 @@ struct agx_ctx {
   bool use_gather = false;   // AGX_KERNEL=gather: one-thread-per-cell gather kernel
   bool use_tile = true;      // AGX_KERNEL=tile (default) | march
   int num_cu = 256;          // persistent workgroups of the tile kernel
+  bool eager_ghosts = true;  // AGX_EAGER_GHOSTS=0: fill ghost cells at the start of agx_iterate
   bool visc_gather = false;  // AGX_VISC=gather: one-thread-per-cell viscous kernel
   int lusgs_mode = 2;        // AGX_LUSGS=plane (0) | brick (1) | pipe (2, default)
   int lusgs_lbi = 8;         // brick length along i (AGX_LBI=8|16)
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
   bool x_in_records = false;    // LU-SGS: newest x is in rec_dyn, SoA planes stale
+  // agx_iterate fills the ghost cells for the NEXT call right after the update,
+  // behind the norm read-back the host waits for, so that the GPU does not idle
+  // while the host turns the iteration around
+  bool in_iterate = false, ghosts_prefilled = false;
+  hipEvent_t norm_event = nullptr;
   bool consn_pending = false;   // AssignSolToTimeN deferred into the next fused stage-0 launch
   long fused_parts = 0;
   // timing: hipEvent pairs recorded on the library's stream around each
@@ -553,6 +559,12 @@ int reduce_norms(agx_ctx* c, size_t blk_index, long nparts) {
   return 0;
 }
 
+// gridLevel::GetBoundaryConditions gridLevel.cpp:287-319 for the blocks of this rank
+int fill_ghosts(agx_ctx* c) {
+  if (agx_phase_bc_faces(c)) return 1;
+  if (agx_halo_swap_local(c, AGX_HALO_STATE)) return 1;
+  return agx_phase_bc_edges(c);
+}
 int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
   const double alpha[4] = {0.25, 1.0 / 3.0, 0.5, 1.0};   // procBlock.cpp:938
   if (mode != 2 && c->fused_pending) {
@@ -587,7 +599,17 @@ int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
                         hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(c->err_host, c->err_dev, sizeof(int),
                         hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));   // the one sync per iteration
+  if (c->in_iterate && mode != 2 && c->eager_ghosts) {
+    // the host waits for the norms only; the ghost fill of the next iteration is
+    // already queued behind them
+    if (!c->norm_event) HIPCHK(hipEventCreateWithFlags(&c->norm_event, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->norm_event, c->stream));
+    if (fill_ghosts(c)) return 1;
+    c->ghosts_prefilled = true;
+    HIPCHK(hipEventSynchronize(c->norm_event));
+  } else {
+    HIPCHK(hipStreamSynchronize(c->stream));   // the one sync per iteration
+  }
   if (check_device_error(c)) return 1;
   for (size_t n = 0; n < c->blocks.size(); ++n) {
     const NormPartial& p = c->norm_host[n];
@@ -636,6 +658,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (ncu > 0) c->num_cu = ncu;
     if (const char* w = getenv("AGX_WORKGROUPS")) c->num_cu = std::max(1, atoi(w));
     if (const char* w = getenv("AGX_VISC")) c->visc_gather = !strcmp(w, "gather");
+    if (const char* w = getenv("AGX_EAGER_GHOSTS")) c->eager_ghosts = atoi(w) != 0;
     if (const char* w = getenv("AGX_LUSGS"))
       c->lusgs_mode = !strcmp(w, "plane") ? 0 : (!strcmp(w, "brick") ? 1 : 2);
     if (const char* w = getenv("AGX_LBI")) c->lusgs_lbi = atoi(w) == 16 ? 16 : 8;
@@ -852,6 +875,7 @@ int agx_setup_finalize(agx_ctx* c) {
 }
 
 int agx_state_upload(agx_ctx* c, int id, const double* state) {
+  c->ghosts_prefilled = false;
   if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
@@ -889,6 +913,7 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
   return download_aos(c, b, out, p, nc, b.d.ni + 2 * g, b.d.nj + 2 * g, b.d.nk + 2 * g, g);
 }
 int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
+  c->ghosts_prefilled = false;
   if (flush_x(c)) return 1;
   if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
@@ -1111,6 +1136,7 @@ int agx_halo_pack(agx_ctx* c, int id, int what, double* dev_buf) {
   return 0;
 }
 int agx_halo_unpack(agx_ctx* c, int id, int what, const double* dev_buf) {
+  c->ghosts_prefilled = false;
   if (flush_x(c)) return 1;
   if (id < 0 || id >= (int)c->conns.size()) return fail("bad connection id");
   Conn& k = c->conns[id];
@@ -1131,10 +1157,12 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
   for (auto& k : c->conns)
     if (my_side(c, k) >= 0)
       return fail("agx_iterate: remote connections need the phase API");
-  // gridLevel::GetBoundaryConditions gridLevel.cpp:287-319
-  if (agx_phase_bc_faces(c)) return 1;
-  if (agx_halo_swap_local(c, AGX_HALO_STATE)) return 1;
-  if (agx_phase_bc_edges(c)) return 1;
+  // gridLevel::GetBoundaryConditions gridLevel.cpp:287-319 (already done behind the
+  // previous call's norm read-back unless something touched the state since)
+  if (!c->ghosts_prefilled && fill_ghosts(c)) return 1;
+  c->ghosts_prefilled = false;
+  struct Scope { agx_ctx* c; ~Scope() { c->in_iterate = false; } } scope{c};
+  c->in_iterate = true;
   // gridLevel::CalcResidual :372-400 + CalcTimeStep :240-247
   if (agx_phase_residual(c, mm, cfl)) return 1;
   *matrix_resid = 0.0;
