@@ -1020,13 +1020,16 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
   const int full = sweep > 0 || c->sp.requires_init;
   bool swept = false;
   for (auto& blk : c->blocks) {
-    const BlockDev& b = blk.d;
+    BlockDev& b = blk.d;
     if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
       if (lusgs_sweep(c, blk, true, full)) return 1;
       swept = true;
     } else {
-      hipLaunchKernelGGL(k_copy5, dim3((b.nplane + 255) / 256), dim3(256), 0,
-                         c->stream, planes(b.xold), planes(b.x), b.nplane);
+      // dplur::DPLUR copies x to xold (linearSolver.cpp:487) and relaxes from the
+      // copy; here the two sets of planes change roles instead.  Ghost cells of
+      // the new x that nobody rewrites (physical boundaries) are never read
+      // (ImplicitLower/Upper only cross physical or connection faces).
+      for (int e = 0; e < AGX_NEQ; ++e) std::swap(b.x[e], b.xold[e]);
       hipLaunchKernelGGL(k_dplur, cell_grid(b, CELL_BLOCK), CELL_BLOCK, 0,
                          c->stream, b, c->gas, c->sp);
     }
@@ -1096,14 +1099,17 @@ int agx_halo_swap_local(agx_ctx* c, int what) {
     double* buf0 = c->halo_buf;                 // what side 0 receives
     double* buf1 = c->halo_buf + n0 * AGX_NEQ;  // what side 1 receives
     // both slices are taken before either insert (multiArray3d.hpp:810-821)
-    if (n0) hipLaunchKernelGGL(k_halo_gather, dim3((n0 + 255) / 256), dim3(256), 0,
-                               c->stream, planes(halo_planes(b1, what)), k.side[0].src, n0, buf0);
-    if (n1) hipLaunchKernelGGL(k_halo_gather, dim3((n1 + 255) / 256), dim3(256), 0,
-                               c->stream, planes(halo_planes(b0, what)), k.side[1].src, n1, buf1);
-    if (n0) hipLaunchKernelGGL(k_halo_scatter, dim3((n0 + 255) / 256), dim3(256), 0,
-                               c->stream, planes(halo_planes(b0, what)), k.side[0].dst, n0, buf0);
-    if (n1) hipLaunchKernelGGL(k_halo_scatter, dim3((n1 + 255) / 256), dim3(256), 0,
-                               c->stream, planes(halo_planes(b1, what)), k.side[1].dst, n1, buf1);
+    const long nmax = std::max(n0, n1);
+    if (nmax > 0) {
+      HaloSide g0{planes(halo_planes(b1, what)), k.side[0].src, n0, buf0};
+      HaloSide g1{planes(halo_planes(b0, what)), k.side[1].src, n1, buf1};
+      hipLaunchKernelGGL(k_halo_gather2, dim3((nmax + 255) / 256, 2), dim3(256), 0, c->stream,
+                         g0, g1);
+      HaloSide p0{planes(halo_planes(b0, what)), k.side[0].dst, n0, buf0};
+      HaloSide p1{planes(halo_planes(b1, what)), k.side[1].dst, n1, buf1};
+      hipLaunchKernelGGL(k_halo_scatter2, dim3((nmax + 255) / 256, 2), dim3(256), 0, c->stream,
+                         p0, p1);
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;

@@ -1394,6 +1394,24 @@ __global__ void k_bc_edges(BlockDev b, GasDev g, int viscous, int* err) {
 // index maps precomputed on the host from GetSwapLoc
 // (boundaryConditions.cpp:3006-3181).  buf is [n][ncomp].
 struct Planes5 { double* p[AGX_NEQ]; };
+// both sides of one local connection in one launch (blockIdx.y = side)
+struct HaloSide { Planes5 a; const long* map; long n; double* buf; };
+__global__ void k_halo_gather2(HaloSide s0, HaloSide s1) {
+  const HaloSide& s = blockIdx.y == 0 ? s0 : s1;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= s.n) return;
+  const long q = s.map[t];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) s.buf[e * s.n + t] = s.a.p[e][q];
+}
+__global__ void k_halo_scatter2(HaloSide s0, HaloSide s1) {
+  const HaloSide& s = blockIdx.y == 0 ? s0 : s1;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= s.n) return;
+  const long q = s.map[t];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) s.a.p[e][q] = s.buf[e * s.n + t];
+}
 __global__ void k_halo_gather(Planes5 a, const long* __restrict__ src, long n,
                               double* __restrict__ buf) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
