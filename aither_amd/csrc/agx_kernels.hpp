@@ -546,7 +546,6 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
   constexpr bool BAL = TJ >= 4;   // SIMD load balancing, see the j-face block
   constexpr int NV = AGX_NEQ + 2;                 // state + wid_i + wid_j
   constexpr int TW = 64 + 2 * H, TR = TJ + 2 * H;
-  constexpr int NW = TJ + 2;
   constexpr int PLANE = TR * TW;                  // doubles per variable
   __shared__ double tile[2][NV][TR][TW];
   __shared__ double sFj[2][TJ + 1][AGX_NEQ][64];  // lower j-face fluxes
