@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--workload", choices=["rk4", "lusgs", "dplur8"], default="rk4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo stages the halo slabs through the host (rehearsal of "
+                         "the multi-rank path with several ranks on one GPU)")
     ap.add_argument("--dims", default=None,
                     help="ni,nj,nk of a non-cubic block (kernel experiments only)")
     args = ap.parse_args()
@@ -179,10 +182,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and args.backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+    elif world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     api = aither_amd.load()
     n = args.size
@@ -191,6 +198,19 @@ def main():
     nonlin = case.deck.nonlinear_iterations
     if world > 1:
         def exchange(items):
+            if args.backend == "gloo":
+                reqs, staged = [], []
+                for peer, tag, send, recv in items:
+                    hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+                    staged.append((recv, hr))
+                    reqs.append(dist.isend(hs, peer, tag=tag))
+                    reqs.append(dist.irecv(hr, peer, tag=tag))
+                for r in reqs:
+                    r.wait()
+                for recv, hr in staged:
+                    recv.copy_(hr)
+                torch.cuda.synchronize()
+                return
             ops = []
             for peer, tag, send, recv in items:
                 ops.append(dist.P2POp(dist.isend, send, peer, tag=tag))
@@ -230,7 +250,8 @@ def main():
     elapsed = time.perf_counter() - t0
     api.check(api.timing_enable(sol.ctx, 0))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not np.all(np.isfinite(l2)) and not os.environ.get("AGX_ABLATE"):
@@ -317,7 +338,9 @@ def main():
                 if args.workload == "rk4" else "one nonlinear iteration",
                 "blocks": 8 if args.workload == "dplur8" else world,
                 "cells_per_gpu": cells_rank,
-                "halo": "RCCL p2p between phases" if world > 1 else "none"},
+                "halo": ("none" if world == 1 else
+                         "RCCL p2p between phases" if args.backend == "nccl" else
+                         "gloo through the host (rehearsal)")},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
