@@ -553,8 +553,16 @@ int bc_pass(agx_ctx* c, bool faces, int viscous) {
 }
 
 int reduce_norms(agx_ctx* c, size_t blk_index, long nparts) {
-  hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, c->stream,
-                     c->partials, nparts, c->norm_out + blk_index);
+  if (nparts > 4096) {
+    // two levels: 64 workgroups fold slices into the scratch behind norm_out
+    NormPartial* tmp = c->norm_out + c->blocks.size();
+    hipLaunchKernelGGL(k_norm_final, dim3(64), dim3(256), 0, c->stream, c->partials, nparts, tmp);
+    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, c->stream, tmp, 64L,
+                       c->norm_out + blk_index);
+  } else {
+    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, c->stream,
+                       c->partials, nparts, c->norm_out + blk_index);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -868,7 +876,7 @@ int agx_setup_finalize(agx_ctx* c) {
   c->n_partials = max_parts;
   HIPCHK(hipMalloc((void**)&c->partials, sizeof(NormPartial) * max_parts));
   const size_t nb = std::max<size_t>(c->blocks.size(), 1);
-  HIPCHK(hipMalloc((void**)&c->norm_out, sizeof(NormPartial) * nb));
+  HIPCHK(hipMalloc((void**)&c->norm_out, sizeof(NormPartial) * (nb + 64)));
   HIPCHK(hipHostMalloc((void**)&c->norm_host, sizeof(NormPartial) * nb));
   c->finalized = true;
   return 0;

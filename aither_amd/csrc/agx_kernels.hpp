@@ -1527,13 +1527,17 @@ k_update(BlockDev b, GasDev g, SolverDev sp, int mode, double alpha, int last_mm
   norm_block_reduce(r, lin0, active, partials + bid);
 }
 
+// Workgroup g of G folds the contiguous slice g of the partials into out[g]
+// (G = 1: the whole array); fixed order, hence run-to-run deterministic.
 __global__ void k_norm_final(const NormPartial* partials, long n, NormPartial* out) {
   __shared__ NormPartial sh[256];
   NormPartial p;
   for (int e = 0; e < AGX_NEQ; ++e) p.l2[e] = 0.0;
   p.vmax = -1.0e300;
   p.lin = 0x7fffffffffffffffLL;
-  for (long t = threadIdx.x; t < n; t += blockDim.x) {
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long t0 = (long)blockIdx.x * per, t1 = min(n, t0 + per);
+  for (long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
     const NormPartial o = partials[t];
     for (int e = 0; e < AGX_NEQ; ++e) p.l2[e] += o.l2[e];
     if (o.vmax > p.vmax || (o.vmax == p.vmax && o.lin < p.lin)) { p.vmax = o.vmax; p.lin = o.lin; }
@@ -1549,7 +1553,7 @@ __global__ void k_norm_final(const NormPartial* partials, long n, NormPartial* o
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out = sh[0];
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
 // procBlock::AssignSolToTimeN / AssignSolToTimeNm1 procBlock.cpp:1037-1054
