@@ -316,8 +316,10 @@ def main():
                 roof["traffic"] = tr["bytes_per_launch"]
                 roof["traffic_detail"] = tr
         out = {
-            "metric": "Mcell-updates/sec per iteration (residual + update), "
-                      f"{n}^3 block",
+            "metric": "Mcell-updates/sec per iteration (" +
+                      {"rk4": "residual + explicit RK4 stage update",
+                       "lusgs": "residual + LU-SGS",
+                       "dplur8": "residual + DPLUR"}[args.workload] + f"), {n}^3 block",
             "value": value, "unit": "Mcell-updates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
