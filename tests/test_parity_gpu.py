@@ -259,6 +259,22 @@ def test_config2_128cubed_one_rk_step(agx, oracle):
     _close(*run_pair(agx, oracle, case, 1, fields=("state", "residual")))
 
 
+def test_config3_88cubed_lusgs_iterations(agx, oracle):
+    """configs[2] at 88^3: WENO5 + AUSMPW+ + viscous, LU-SGS.  11^3 = 1331 bricks,
+    more than the 1024 waves the single-launch sweep keeps resident, so the ticket
+    queue wraps and bricks wait on predecessors that other waves are still
+    working on."""
+    wall = {3: ("viscousWall", 2), 1: ("characteristic", 1),
+            2: ("characteristic", 1), 4: ("characteristic", 1)}
+    case = synthetic.single_block_case(n=(88, 88, 88), stretch=1.2, bcs=wall,
+                                       equation_set="navierStokes",
+                                       face_reconstruction="weno", limiter="none",
+                                       inviscid_flux="ausm",
+                                       time_integration="implicitEuler",
+                                       matrix_solver="lusgs", cfl=10.0)
+    _close(*run_pair(agx, oracle, case, 2, fields=("state", "residual")))
+
+
 def test_256cubed_freestream_and_conservation(agx):
     """Full-size properties that need no oracle:
     (a) a uniform state on a stretched grid with far-field BCs has zero
