@@ -5,7 +5,8 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaither_gfx950.so")
+# AGX_LIB: a diagnostic build of the same library (e.g. -DAGX_KP_TRACE)
+LIB_PATH = os.environ.get("AGX_LIB") or os.path.join(_HERE, "libaither_gfx950.so")
 _api = None
 
 

@@ -39,9 +39,16 @@ struct Block {
   BlockDev d;
   int global_pos = 0;
   double* slab = nullptr;
-  double* rec = nullptr;      // LU-SGS sweep records
-  int* pipe_mem = nullptr;    // k_lusgs_pipe: brick order | done flags | ticket
-  int pipe_total = 0, pipe_epoch = 0, pipe_lbi = 0;
+  double* d2 = nullptr;       // D2 arrays of the LU-SGS path (agx_lusgs.hpp)
+  int* d2_tab = nullptr;      // device: dstart[Pi + Pj] | ij_of_pos[Pi * Pj]
+  std::vector<int> dstart;    // host copy (halo index maps)
+  int* kp_mem = nullptr;      // k_lusgs_kp: progress flag per k-plane | ticket
+  int kp_epoch = 0;
+  // D2 index of padded cell (i, j, k), host side
+  long d2idx(int i, int j, int k) const {
+    const int ie = i + d.ng, je = j + d.ng, de = ie + je;
+    return (long)(k + d.ng) * d.d2.ps + dstart[de] + je - std::max(0, de - (d.d2.Pi - 1));
+  }
   bool state_is_a = true;
   agx_bc_surface* surf_dev = nullptr;
   std::vector<agx_bc_surface> surf_host;
@@ -51,6 +58,8 @@ struct ConnSide {          // what side s receives / sends
   long n = 0;              // cells inserted into side s
   long* dst = nullptr;     // device: ghost cells of side s (this rank's block)
   long* src = nullptr;     // device: partner cells that fill them
+  long* dst2 = nullptr;    // the same cells in D2 index space (x of the LU-SGS path)
+  long* src2 = nullptr;
 };
 struct Conn {
   agx_connection c;
@@ -58,6 +67,7 @@ struct Conn {
   // for remote connections: cells of MY block that the partner's ghosts read
   long n_send = 0;
   long* send_src = nullptr;
+  long* send_src2 = nullptr;
 };
 
 enum { G_RESID = 0, G_UPDATE = 1, G_BC = 2, G_SWEEP = 3, G_NGROUP = 4 };
@@ -86,11 +96,11 @@ struct agx_ctx {
   int num_cu = 256;          // persistent workgroups of the tile kernel
   bool eager_ghosts = true;  // AGX_EAGER_GHOSTS=0: fill ghost cells at the start of agx_iterate
   bool visc_gather = false;  // AGX_VISC=gather: one-thread-per-cell viscous kernel
-  int lusgs_mode = 2;        // AGX_LUSGS=plane (0) | brick (1) | pipe (2, default)
-  int lusgs_lbi = 8;         // brick length along i (AGX_LBI=8|16)
+  int lusgs_mode = 1;        // AGX_LUSGS=plane (0: launch per hyperplane on the SoA
+                             // planes, comparison form) | kp (1, default: agx_lusgs.hpp)
+  int spin_limit = 4000000;  // AGX_SPIN_LIMIT: polls before a waiting plane gives up
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
-  bool x_in_records = false;    // LU-SGS: newest x is in rec_dyn, SoA planes stale
   // agx_iterate fills the ghost cells for the NEXT call right after the update,
   // behind the norm read-back the host waits for, so that the GPU does not idle
   // while the host turns the iteration around
@@ -176,6 +186,7 @@ const dim3 CELL_BLOCK(64, 4, 1);
 Planes5 planes(double* const* p, int n = AGX_NEQ) {
   Planes5 r;
   for (int e = 0; e < AGX_NEQ; ++e) r.p[e] = e < n ? p[e] : nullptr;
+  r.stride = 1;
   return r;
 }
 
@@ -290,8 +301,17 @@ int ensure_halo_buf(agx_ctx* c, long ndoubles) {
   return 0;
 }
 
-double* const* halo_planes(Block& b, int what) {
-  return what == AGX_HALO_STATE ? b.d.state : b.d.x;
+// what a halo exchange moves: the state planes, or x -- which the D2 LU-SGS path
+// keeps in its own arrays and index space (maps dst2 / src2)
+bool halo_in_d2(const Block& b, int what) { return what == AGX_HALO_UPDATE && b.d.d2.base; }
+Planes5 halo_planes(Block& b, int what) {
+  Planes5 r;
+  const bool z2 = halo_in_d2(b, what);
+  r.stride = z2 ? 2 : 1;     // x of the D2 path sits in pair arrays (x0,x1) (x2,x3) (x4,-)
+  for (int e = 0; e < AGX_NEQ; ++e)
+    r.p[e] = what == AGX_HALO_STATE ? b.d.state[e]
+             : (z2 ? b.d.d2.base + 2L * (PA_X + (e >> 1)) * b.d.d2.nd2 + (e & 1) : b.d.x[e]);
+  return r;
 }
 
 int check_device_error(agx_ctx* c) {
@@ -300,8 +320,8 @@ int check_device_error(agx_ctx* c) {
     *c->err_host = 0;
     hipMemsetAsync(c->err_dev, 0, sizeof(int), c->stream);
     if (code == 2)
-      return fail("LU-SGS pipeline: a brick waited beyond the spin limit for its "
-                  "predecessors (AGX_LUSGS=brick selects the launch-per-plane form)");
+      return fail("LU-SGS pipeline: a k-plane waited beyond the spin limit for its "
+                  "predecessor (AGX_LUSGS=plane selects the launch-per-hyperplane form)");
     return fail("a boundary-condition variant outside this build's coverage "
                 "was requested (nonreflecting inlet/outlet)");
   }
@@ -408,73 +428,97 @@ bool can_fuse(const agx_ctx* c) {
   return c->allow_fuse && !c->use_gather && !c->sp.implicit && !c->sp.viscous;
 }
 
-// One LU-SGS half sweep over a block: coarse hyperplanes of LBI x 8 x 8 bricks,
-// one launch each (k_lusgs_brick); AGX_LUSGS=plane selects the one-launch-per-
-// fine-hyperplane form kept for comparison.
-template <bool FWD, int LBI>
-void lusgs_brick_launches(agx_ctx* c, const BlockDev& b, int full) {
-  const int nbi = (b.ni + LBI - 1) / LBI, nbj = (b.nj + 7) / 8, nbk = (b.nk + 7) / 8;
-  const dim3 tb(64, 4), grid((nbj * nbk + 3) / 4);
-  const int ncp = nbi + nbj + nbk - 2;
-  for (int t = 0; t < ncp; ++t) {
-    const int p = FWD ? t : ncp - 1 - t;
-    hipLaunchKernelGGL((k_lusgs_brick<FWD, LBI>), grid, tb, 0, c->stream, b, c->gas,
-                       c->sp, p, full, nbi, nbj, nbk);
-  }
+// the D2 LU-SGS path (agx_lusgs.hpp) serves scalar LU-SGS unless AGX_LUSGS=plane
+bool use_d2(const agx_ctx* c) {
+  return c->sp.implicit && c->cfg.matrix_solver == AGX_SOLVER_LUSGS && c->lusgs_mode == 1;
 }
-// x of the brick sweeps lives in the records until somebody needs the SoA planes
-int flush_x(agx_ctx* c) {
-  if (!c->x_in_records) return 0;
-  c->x_in_records = false;
-  for (auto& blk : c->blocks)
-    hipLaunchKernelGGL(k_lusgs_unpack, dim3((blk.d.nplane + 255) / 256), dim3(256), 0,
-                       c->stream, blk.d);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-template <bool FWD, int LBI>
-int lusgs_pipe_launch(agx_ctx* c, Block& blk, int full) {
+// One LU-SGS half sweep over a block, one launch: a workgroup per k-plane marches
+// the plane's diagonals, the planes follow each other one step apart (k_lusgs_kp).
+template <bool FWD, bool FULL, bool CONN, int CH>
+int lusgs_kp_launch(agx_ctx* c, Block& blk) {
   const BlockDev& b = blk.d;
-  const int nbi = (b.ni + LBI - 1) / LBI, nbj = (b.nj + 7) / 8, nbk = (b.nk + 7) / 8;
-  const int total = nbi * nbj * nbk;
-  if (!blk.pipe_mem || blk.pipe_lbi != LBI) {
-    // brick ids in coarse-plane order (any topological order would do)
-    std::vector<int> order;
-    order.reserve(total);
-    for (int p = 0; p <= nbi + nbj + nbk - 3; ++p)
-      for (int bk = 0; bk < nbk; ++bk)
-        for (int bj = 0; bj < nbj; ++bj) {
-          const int bi = p - bj - bk;
-          if (bi >= 0 && bi < nbi) order.push_back(bi + nbi * (bj + nbj * bk));
-        }
-    if (blk.pipe_mem) hipFree(blk.pipe_mem);
-    HIPCHK(hipMalloc((void**)&blk.pipe_mem, sizeof(int) * (2 * (size_t)total + 1)));
-    HIPCHK(hipMemcpyAsync(blk.pipe_mem, order.data(), sizeof(int) * total,
-                          hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));     // `order` is a stack vector
-    HIPCHK(hipMemsetAsync(blk.pipe_mem + total, 0, sizeof(int) * ((size_t)total + 1), c->stream));
-    blk.pipe_total = total; blk.pipe_epoch = 0; blk.pipe_lbi = LBI;
+  if (!blk.kp_mem) {
+    HIPCHK(hipMalloc((void**)&blk.kp_mem, sizeof(int) * ((size_t)b.nk + 1)));
+    HIPCHK(hipMemsetAsync(blk.kp_mem, 0, sizeof(int) * ((size_t)b.nk + 1), c->stream));
+    blk.kp_epoch = 0;
   }
-  LusgsPipe pp;
-  pp.order = blk.pipe_mem;
-  pp.flags = blk.pipe_mem + total;
-  pp.ticket = blk.pipe_mem + 2 * total;
-  pp.err = c->err_dev;
-  pp.total = total;
-  pp.epoch = ++blk.pipe_epoch;
-  pp.spin_limit = getenv("AGX_SPIN_LIMIT") ? atoi(getenv("AGX_SPIN_LIMIT")) : 4000000;
-  HIPCHK(hipMemsetAsync(pp.ticket, 0, sizeof(int), c->stream));
-  // persistent: as many workgroups as are resident at once (the kernel's register
-  // use decides; asked from the runtime), never more than there are bricks
+  if (blk.kp_epoch >= 30000) {   // flags hold epoch << 16 | steps: restart before it wraps
+    HIPCHK(hipMemsetAsync(blk.kp_mem, 0, sizeof(int) * ((size_t)b.nk + 1), c->stream));
+    blk.kp_epoch = 0;
+  }
+  KpArgs kp;
+  kp.flags = blk.kp_mem;
+  kp.ticket = blk.kp_mem + b.nk;
+  kp.err = c->err_dev;
+  kp.epoch = ++blk.kp_epoch;
+  kp.spin_limit = c->spin_limit;
+  kp.trace = nullptr;
+#ifdef AGX_KP_TRACE
+  static long long* trace_dev = nullptr;
+  const size_t trace_n = 6 * (size_t)(b.ni + b.nj + 2);
+  if (getenv("AGX_KP_TRACE")) {
+    if (!trace_dev) hipMalloc((void**)&trace_dev, sizeof(long long) * 6 * 8192);
+    hipMemsetAsync(trace_dev, 0, sizeof(long long) * trace_n, c->stream);
+    kp.trace = trace_dev;
+  }
+#endif
+  HIPCHK(hipMemsetAsync(kp.ticket, 0, sizeof(int), c->stream));
+  // LDS: two buffers of 14-double records for the cells of a diagonal (+ 2 slots)
+  int nsl = std::min(b.ni, b.nj) + 2;
+  nsl += nsl & 1;
+  const size_t lds = sizeof(double) * 2 * KP_NV * (size_t)nsl;
+  const void* fn = reinterpret_cast<const void*>(&k_lusgs_kp<FWD, FULL, CONN, CH>);
+  if (lds > 48 * 1024)
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // persistent: never more workgroups than are resident at once (a plane waits
+  // for its predecessor, which must therefore be running or finished)
   int per_cu = 1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &per_cu, reinterpret_cast<const void*>(&k_lusgs_pipe<FWD, LBI>), 256, 0) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess ||
       per_cu < 1)
     per_cu = 1;
-  const int wgs = std::min(per_cu * c->num_cu, (total + 3) / 4);
-  hipLaunchKernelGGL((k_lusgs_pipe<FWD, LBI>), dim3(wgs), dim3(64, 4), 0, c->stream, b,
-                     c->gas, c->sp, full, nbi, nbj, nbk, pp);
+  const int wgs = std::min(per_cu * c->num_cu, b.nk);
+  KpBlk kb;
+  kb.base = b.d2.base; kb.dstart = b.d2.dstart; kb.surf = b.surf;
+  kb.nd2 = b.d2.nd2; kb.ps = b.d2.ps; kb.Pi = b.d2.Pi; kb.Pj = b.d2.Pj;
+  kb.ni = b.ni; kb.nj = b.nj; kb.nk = b.nk; kb.ng = b.ng;
+  kb.nsurf = b.nsurf; kb.nsurf_i = b.nsurf_i; kb.nsurf_j = b.nsurf_j; kb.nsurf_k = b.nsurf_k;
+  for (int q = 0; q < 6; ++q) kb.side_conn[q] = b.side_conn[q];
+  const KpGas kg{c->gas.hf, c->gas.n, c->gas.inv_n};
+  hipLaunchKernelGGL((k_lusgs_kp<FWD, FULL, CONN, CH>), dim3(wgs), dim3(256), lds, c->stream,
+                     kb, kg, c->sp.viscous, nsl, kp);
+#ifdef AGX_KP_TRACE
+  if (kp.trace) {   // diagnostic build only: dump the step timestamps of this launch
+    std::vector<long long> h(trace_n);
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(h.data(), kp.trace, sizeof(long long) * trace_n, hipMemcpyDeviceToHost);
+    FILE* f = fopen(getenv("AGX_KP_TRACE"), "a");
+    if (f) {
+      fprintf(f, "# %s ni %d nj %d nk %d wgs %d\n", FWD ? "fwd" : "bwd", b.ni, b.nj, b.nk, wgs);
+      for (size_t t = 0; t + 6 <= trace_n; t += 6)
+        fprintf(f, "%lld %lld %lld %lld %lld %lld\n", h[t], h[t + 1], h[t + 2], h[t + 3],
+                h[t + 4], h[t + 5]);
+      fclose(f);
+    }
+  }
+#endif
   return 0;
+}
+// diagonals longer than 256 cells are walked in CH chunks per step
+constexpr int KP_MAX_DIAG = 512;   // LDS: 2 * 19 * 8 * (n + 2) bytes <= 160 KiB
+template <bool FWD, bool FULL, bool CONN>
+int lusgs_kp_chunks(agx_ctx* c, Block& blk) {
+  const int n = std::min(blk.d.ni, blk.d.nj);
+  if (n <= 256) return lusgs_kp_launch<FWD, FULL, CONN, 1>(c, blk);
+  return lusgs_kp_launch<FWD, FULL, CONN, 2>(c, blk);
+}
+template <bool FWD>
+int lusgs_kp_variant(agx_ctx* c, Block& blk, int full) {
+  bool conn = false;
+  for (int q = 0; q < 6; ++q) conn = conn || blk.d.side_conn[q] != 0;
+  if (full) return conn ? lusgs_kp_chunks<FWD, true, true>(c, blk)
+                        : lusgs_kp_chunks<FWD, true, false>(c, blk);
+  return conn ? lusgs_kp_chunks<FWD, false, true>(c, blk)
+              : lusgs_kp_chunks<FWD, false, false>(c, blk);
 }
 
 int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full) {
@@ -493,24 +537,7 @@ int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full) {
     }
     return 0;
   }
-  if (!c->x_in_records)
-    hipLaunchKernelGGL(k_lusgs_pack, dim3((b.nplane + 255) / 256), dim3(256), 0, c->stream,
-                       b, c->gas, c->sp);
-  if (c->lusgs_mode == 2) {
-    if (c->lusgs_lbi == 8)
-      return forward ? lusgs_pipe_launch<true, 8>(c, blk, full)
-                     : lusgs_pipe_launch<false, 8>(c, blk, full);
-    return forward ? lusgs_pipe_launch<true, 16>(c, blk, full)
-                   : lusgs_pipe_launch<false, 16>(c, blk, full);
-  }
-  if (c->lusgs_lbi == 8) {
-    if (forward) lusgs_brick_launches<true, 8>(c, b, full);
-    else lusgs_brick_launches<false, 8>(c, b, full);
-  } else {
-    if (forward) lusgs_brick_launches<true, 16>(c, b, full);
-    else lusgs_brick_launches<false, 16>(c, b, full);
-  }
-  return 0;
+  return forward ? lusgs_kp_variant<true>(c, blk, full) : lusgs_kp_variant<false>(c, blk, full);
 }
 
 // consVarsN = cons(state) that agx_store_time_n deferred (see there)
@@ -594,8 +621,15 @@ int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
     Timer t(c, G_UPDATE);
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       const BlockDev& b = c->blocks[n].d;
-      const dim3 grid = cell_grid(b, CELL_BLOCK);
       const int last = mm == c->cfg.nonlinear_iterations - 1;
+      if (mode == 2 && b.d2.base) {
+        const dim3 tg((b.ni + TT - 1) / TT, (b.nj + TT - 1) / TT, b.nk);
+        hipLaunchKernelGGL(k_update_d2, tg, dim3(256), 0, c->stream, b, c->gas, c->sp, last,
+                           c->partials);
+        if (reduce_norms(c, n, (long)tg.x * tg.y * tg.z)) return 1;
+        continue;
+      }
+      const dim3 grid = cell_grid(b, CELL_BLOCK);
       hipLaunchKernelGGL(k_update, grid, CELL_BLOCK, 0, c->stream, b, c->gas,
                          c->sp, mode, mode == 1 ? alpha[mm & 3] : 1.0, last,
                          c->partials);
@@ -667,9 +701,8 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_WORKGROUPS")) c->num_cu = std::max(1, atoi(w));
     if (const char* w = getenv("AGX_VISC")) c->visc_gather = !strcmp(w, "gather");
     if (const char* w = getenv("AGX_EAGER_GHOSTS")) c->eager_ghosts = atoi(w) != 0;
-    if (const char* w = getenv("AGX_LUSGS"))
-      c->lusgs_mode = !strcmp(w, "plane") ? 0 : (!strcmp(w, "brick") ? 1 : 2);
-    if (const char* w = getenv("AGX_LBI")) c->lusgs_lbi = atoi(w) == 16 ? 16 : 8;
+    if (const char* w = getenv("AGX_LUSGS")) c->lusgs_mode = !strcmp(w, "plane") ? 0 : 1;
+    if (const char* w = getenv("AGX_SPIN_LIMIT")) c->spin_limit = std::max(1, atoi(w));
   }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
   HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
@@ -685,16 +718,20 @@ void agx_ctx_destroy(agx_ctx* c) {
   hipStreamSynchronize(c->stream);
   for (auto& b : c->blocks) {
     if (b.slab) hipFree(b.slab);
-    if (b.rec) hipFree(b.rec);
-    if (b.pipe_mem) hipFree(b.pipe_mem);
+    if (b.d2) hipFree(b.d2);
+    if (b.d2_tab) hipFree(b.d2_tab);
+    if (b.kp_mem) hipFree(b.kp_mem);
     if (b.surf_dev) hipFree(b.surf_dev);
   }
   for (auto& k : c->conns) {
     for (int s = 0; s < 2; ++s) {
       if (k.side[s].dst) hipFree(k.side[s].dst);
       if (k.side[s].src) hipFree(k.side[s].src);
+      if (k.side[s].dst2) hipFree(k.side[s].dst2);
+      if (k.side[s].src2) hipFree(k.side[s].src2);
     }
     if (k.send_src) hipFree(k.send_src);
+    if (k.send_src2) hipFree(k.send_src2);
   }
   if (c->partials) hipFree(c->partials);
   if (c->norm_out) hipFree(c->norm_out);
@@ -771,12 +808,33 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
     for (int cc = 0; cc < 4; ++cc) d.fa[q][cc] = pl(PL_FA + 4 * q + cc);
   }
   b.state_is_a = true;
-  if (c->sp.implicit && c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
-    // two 128-byte records per cell for the LU-SGS sweeps (k_lusgs_brick)
-    HIPCHK(hipMalloc((void**)&b.rec, sizeof(double) * d.nplane * LREC * 2));
-    d.rec_dyn = b.rec;
-    d.rec_geo = b.rec + d.nplane * LREC;
-    HIPCHK(hipMemsetAsync(b.rec, 0, sizeof(double) * d.nplane * LREC * 2, c->stream));
+  if (use_d2(c) && std::min(d.ni, d.nj) > KP_MAX_DIAG)
+    return fail("LU-SGS: a block with min(ni, nj) = %d exceeds the %d cells per diagonal "
+                "the sweep kernel holds in LDS (AGX_LUSGS=plane has no such limit)",
+                std::min(d.ni, d.nj), KP_MAX_DIAG);
+  if (use_d2(c)) {
+    // diagonal-ordered arrays of the LU-SGS path (agx_lusgs.hpp)
+    D2Dev& z = d.d2;
+    z.Pi = d.ni + 2 * d.ng; z.Pj = d.nj + 2 * d.ng;
+    z.ps = ((long)z.Pi * z.Pj + 15) / 16 * 16;
+    z.nd2 = z.ps * (d.nk + 2 * d.ng);
+    b.dstart.assign(z.Pi + z.Pj + 1, 0);
+    std::vector<int> tab(z.Pi + z.Pj + 1 + (size_t)z.Pi * z.Pj);
+    for (int de = 0; de < z.Pi + z.Pj - 1; ++de) {
+      const int jl = std::max(0, de - (z.Pi - 1)), jh = std::min(z.Pj - 1, de);
+      b.dstart[de + 1] = b.dstart[de] + (jh - jl + 1);
+      for (int je = jl; je <= jh; ++je)
+        tab[z.Pi + z.Pj + 1 + b.dstart[de] + (je - jl)] = (de - je) | (je << 16);
+    }
+    b.dstart[z.Pi + z.Pj] = b.dstart[z.Pi + z.Pj - 1];
+    std::copy(b.dstart.begin(), b.dstart.end(), tab.begin());
+    HIPCHK(hipMalloc((void**)&b.d2_tab, sizeof(int) * tab.size()));
+    HIPCHK(hipMemcpy(b.d2_tab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+    z.dstart = b.d2_tab;
+    z.ij_of_pos = b.d2_tab + z.Pi + z.Pj + 1;
+    HIPCHK(hipMalloc((void**)&b.d2, sizeof(double) * z.nd2 * D2_DOUBLES));
+    HIPCHK(hipMemsetAsync(b.d2, 0, sizeof(double) * z.nd2 * D2_DOUBLES, c->stream));
+    z.base = b.d2;
   }
   const int ci = d.ni + 2 * d.ng, cj = d.nj + 2 * d.ng, ck = d.nk + 2 * d.ng;
   if (upload_aos(c, b, g->farea_i, d.fa[0], 4, ci + 1, cj, ck, d.ng)) return 1;
@@ -790,8 +848,10 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
     double* wp[1] = {d.wid[q]};
     if (upload_aos(c, b, wsrc[q], wp, 1, ci, cj, ck, d.ng)) return 1;
   }
-  if (d.rec_geo)
-    hipLaunchKernelGGL(k_lusgs_geo, dim3((d.nplane + 255) / 256), dim3(256), 0, c->stream, d);
+  if (d.d2.base) {
+    const long n = (long)d.d2.Pi * d.d2.Pj * (d.nk + 2 * d.ng);
+    hipLaunchKernelGGL(k_d2_geo, dim3((n + 255) / 256), dim3(256), 0, c->stream, d);
+  }
   HIPCHK(hipGetLastError());
   if (g->wall_dist) {
     double* wp[1] = {d.wdist};
@@ -811,12 +871,16 @@ int agx_block_set_bcs(agx_ctx* c, int id, int n, const agx_bc_surface* s) {
   b.d.surf = b.surf_dev;
   b.d.nsurf = n;
   b.d.nsurf_i = b.d.nsurf_j = b.d.nsurf_k = 0;
+  int n_conn[6] = {0, 0, 0, 0, 0, 0}, n_other[6] = {0, 0, 0, 0, 0, 0};
   for (int q = 0; q < n; ++q) {
     const int st = surface_type(s[q]);
     if (st <= 2) b.d.nsurf_i++; else if (st <= 4) b.d.nsurf_j++; else b.d.nsurf_k++;
     const int t = s[q].bc_type;
     if (t < AGX_BC_SLIPWALL || t > AGX_BC_PERIODIC) return fail("unknown bc type %d", t);
+    if (t == AGX_BC_INTERBLOCK || t == AGX_BC_PERIODIC) n_conn[st - 1]++; else n_other[st - 1]++;
   }
+  for (int q = 0; q < 6; ++q)
+    b.d.side_conn[q] = n_conn[q] == 0 ? 0 : (n_other[q] == 0 ? 1 : 2);
   return 0;
 }
 
@@ -836,6 +900,8 @@ int agx_setup_finalize(agx_ctx* c) {
     const dim3 g = cell_grid(blk.d, CELL_BLOCK);
     max_parts = std::max(max_parts, (long)g.x * g.y * g.z);
     march_parts += march_plan(c, blk.d).nparts;
+    if (blk.d.d2.base)    // k_matrix_resid_d2: one partial per 256 plane positions
+      max_parts = std::max(max_parts, (((long)blk.d.d2.Pi * blk.d.d2.Pj + 255) / 256) * blk.d.nk);
   }
   max_parts = std::max(max_parts, march_parts);
   for (auto& k : c->conns) {
@@ -870,6 +936,25 @@ int agx_setup_finalize(agx_ctx* c) {
       if (to_device(m.dst, &k.side[s].dst)) return 1;
       if (partner_mine && to_device(m.src, &k.side[s].src)) return 1;
       max_halo = std::max(max_halo, (long)m.dst.size() * AGX_NEQ);
+      if (use_d2(c)) {
+        // the same maps in D2 index space: x of the LU-SGS path lives there
+        const Block& Br = c->blocks[lb];
+        auto idxR2 = [&](int i, int j, int kk) { return Br.d2idx(i, j, kk); };
+        MapOut m2;
+        if (partner_mine) {
+          const Block& Bs = c->blocks[cc.local_block[1 - s]];
+          auto idxS2 = [&](int i, int j, int kk) { return Bs.d2idx(i, j, kk); };
+          build_side_map(cc, s, ng, idxR2, idxS2, m2);
+          if (to_device(m2.src, &k.side[s].src2)) return 1;
+        } else {
+          auto idxS0 = [&](int, int, int) { return 0L; };
+          build_side_map(cc, s, ng, idxR2, idxS0, m2);
+          MapOut ms2;
+          build_side_map(cc, 1 - s, ng, idxS0, idxR2, ms2);
+          if (to_device(ms2.src, &k.send_src2)) return 1;
+        }
+        if (to_device(m2.dst, &k.side[s].dst2)) return 1;
+      }
     }
   }
   if (ensure_halo_buf(c, 2 * max_halo)) return 1;
@@ -908,11 +993,19 @@ static int field_info(Block& b, int field, double* const** p, int* ncomp, int* g
   return 1;
 }
 
+// x of the D2 LU-SGS path <-> the SoA planes the field transfers use
+static int d2_x_copy(agx_ctx* c, Block& b, int to_d2) {
+  const long n = (long)b.d.d2.Pi * b.d.d2.Pj * (b.d.nk + 2 * b.d.ng);
+  hipLaunchKernelGGL(k_d2_x_copy, dim3((n + 255) / 256), dim3(256), 0, c->stream, b.d, to_d2);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int agx_field_download(agx_ctx* c, int id, int field, double* out) {
-  if (flush_x(c)) return 1;
   if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
+  if (field == AGX_FIELD_UPDATE && b.d.d2.base && d2_x_copy(c, b, 0)) return 1;
   double* const* p; int nc, gh;
   if (field_info(b, field, &p, &nc, &gh))
     return fail("field %d is not stored by this library (temperature and "
@@ -922,14 +1015,15 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
 }
 int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
   c->ghosts_prefilled = false;
-  if (flush_x(c)) return 1;
   if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
   double* const* p; int nc, gh;
   if (field_info(b, field, &p, &nc, &gh)) return fail("field %d cannot be uploaded", field);
   const int g = gh ? b.d.ng : 0;
-  return upload_aos(c, b, in, p, nc, b.d.ni + 2 * g, b.d.nj + 2 * g, b.d.nk + 2 * g, g);
+  if (upload_aos(c, b, in, p, nc, b.d.ni + 2 * g, b.d.nj + 2 * g, b.d.nk + 2 * g, g)) return 1;
+  if (field == AGX_FIELD_UPDATE && b.d.d2.base) return d2_x_copy(c, b, 1);
+  return 0;
 }
 
 int agx_store_time_n(agx_ctx* c, int also_nm1) {
@@ -1009,10 +1103,15 @@ int agx_phase_explicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
 }
 
 int agx_phase_implicit_begin(agx_ctx* c) {
-  if (flush_x(c)) return 1;
   Timer t(c, G_SWEEP);
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
+    if (b.d2.base) {
+      // diagonal terms, b and x0 straight into the D2 arrays of the sweeps
+      const dim3 grid((b.d2.Pi + TT - 1) / TT, (b.d2.Pj + TT - 1) / TT, b.nk + 2 * b.ng);
+      hipLaunchKernelGGL(k_lusgs_prepare, grid, dim3(256), 0, c->stream, b, c->gas, c->sp);
+      continue;
+    }
     if (!c->sp.requires_init)   // x_[bb].Zero() incl. ghosts, linearSolver.cpp:141
       hipLaunchKernelGGL(k_zero5, dim3((b.nplane + 255) / 256), dim3(256), 0,
                          c->stream, planes(b.x), b.nplane);
@@ -1042,7 +1141,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
                          c->stream, b, c->gas, c->sp);
     }
   }
-  if (swept && c->lusgs_mode != 0) c->x_in_records = true;
+  (void)swept;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1054,19 +1153,24 @@ int agx_phase_relax_backward(agx_ctx* c, int sweep) {
   for (auto& blk : c->blocks) {
     if (lusgs_sweep(c, blk, false, full)) return 1;
   }
-  if (c->lusgs_mode != 0) c->x_in_records = true;
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
-  if (flush_x(c)) return 1;
   double sumsq = 0.0;
   long size = 0;
   {
     Timer t(c, G_SWEEP);
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       const BlockDev& b = c->blocks[n].d;
+      if (b.d2.base) {
+        const dim3 grid(((long)b.d2.Pi * b.d2.Pj + 255) / 256, b.nk);
+        hipLaunchKernelGGL(k_matrix_resid_d2, grid, dim3(256), 0, c->stream, b, c->gas,
+                           c->sp, c->partials);
+        if (reduce_norms(c, n, (long)grid.x * grid.y)) return 1;
+        continue;
+      }
       const dim3 grid = cell_grid(b, CELL_BLOCK);
       hipLaunchKernelGGL(k_matrix_resid, grid, CELL_BLOCK, 0, c->stream, b,
                          c->gas, c->sp, c->partials);
@@ -1088,14 +1192,12 @@ int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
 }
 
 int agx_phase_implicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
-  if (flush_x(c)) return 1;
   return update_pass(c, 2, mm, l2, linf);
 }
 
 // ---- halo -----------------------------------------------------------------
 int agx_halo_swap_local(agx_ctx* c, int what) {
   if (c->conns.empty()) return 0;
-  if (flush_x(c)) return 1;
   Timer t(c, G_BC);
   for (auto& k : c->conns) {
     const agx_connection& cc = k.c;
@@ -1109,12 +1211,13 @@ int agx_halo_swap_local(agx_ctx* c, int what) {
     // both slices are taken before either insert (multiArray3d.hpp:810-821)
     const long nmax = std::max(n0, n1);
     if (nmax > 0) {
-      HaloSide g0{planes(halo_planes(b1, what)), k.side[0].src, n0, buf0};
-      HaloSide g1{planes(halo_planes(b0, what)), k.side[1].src, n1, buf1};
+      const bool z2 = halo_in_d2(b0, what);
+      HaloSide g0{halo_planes(b1, what), z2 ? k.side[0].src2 : k.side[0].src, n0, buf0};
+      HaloSide g1{halo_planes(b0, what), z2 ? k.side[1].src2 : k.side[1].src, n1, buf1};
       hipLaunchKernelGGL(k_halo_gather2, dim3((nmax + 255) / 256, 2), dim3(256), 0, c->stream,
                          g0, g1);
-      HaloSide p0{planes(halo_planes(b0, what)), k.side[0].dst, n0, buf0};
-      HaloSide p1{planes(halo_planes(b1, what)), k.side[1].dst, n1, buf1};
+      HaloSide p0{halo_planes(b0, what), z2 ? k.side[0].dst2 : k.side[0].dst, n0, buf0};
+      HaloSide p1{halo_planes(b1, what), z2 ? k.side[1].dst2 : k.side[1].dst, n1, buf1};
       hipLaunchKernelGGL(k_halo_scatter2, dim3((nmax + 255) / 256, 2), dim3(256), 0, c->stream,
                          p0, p1);
     }
@@ -1137,7 +1240,6 @@ int64_t agx_halo_count(agx_ctx* c, int id, int what) {
   return (int64_t)AGX_NEQ * std::max(k.n_send, k.side[s].n);
 }
 int agx_halo_pack(agx_ctx* c, int id, int what, double* dev_buf) {
-  if (flush_x(c)) return 1;
   if (id < 0 || id >= (int)c->conns.size()) return fail("bad connection id");
   Conn& k = c->conns[id];
   const int s = my_side(c, k);
@@ -1145,13 +1247,13 @@ int agx_halo_pack(agx_ctx* c, int id, int what, double* dev_buf) {
   Block& b = c->blocks[k.c.local_block[s]];
   const long n = k.n_send;
   if (n) hipLaunchKernelGGL(k_halo_gather, dim3((n + 255) / 256), dim3(256), 0,
-                            c->stream, planes(halo_planes(b, what)), k.send_src, n, dev_buf);
+                            c->stream, halo_planes(b, what),
+                            halo_in_d2(b, what) ? k.send_src2 : k.send_src, n, dev_buf);
   HIPCHK(hipGetLastError());
   return 0;
 }
 int agx_halo_unpack(agx_ctx* c, int id, int what, const double* dev_buf) {
   c->ghosts_prefilled = false;
-  if (flush_x(c)) return 1;
   if (id < 0 || id >= (int)c->conns.size()) return fail("bad connection id");
   Conn& k = c->conns[id];
   const int s = my_side(c, k);
@@ -1159,7 +1261,8 @@ int agx_halo_unpack(agx_ctx* c, int id, int what, const double* dev_buf) {
   Block& b = c->blocks[k.c.local_block[s]];
   const long n = k.side[s].n;
   if (n) hipLaunchKernelGGL(k_halo_scatter, dim3((n + 255) / 256), dim3(256), 0,
-                            c->stream, planes(halo_planes(b, what)), k.side[s].dst, n, dev_buf);
+                            c->stream, halo_planes(b, what),
+                            halo_in_d2(b, what) ? k.side[s].dst2 : k.side[s].dst, n, dev_buf);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -12,6 +12,7 @@
 // is converted at upload/download only.)
 #pragma once
 #include "agx_device.hpp"
+#include "agx_lusgs.hpp"
 
 namespace agx {
 
@@ -36,10 +37,12 @@ struct BlockDev {
   double* a;                  // linearSolver::a_ (scalar flow part)
   double* ainv;               // linearSolver::aInv_
   double* wdist;              // wallDist_                procBlock.hpp:88
-  double* rec_dyn;            // LU-SGS sweep records, 16 doubles per cell (below)
-  double* rec_geo;
+  D2Dev d2;                   // diagonal-ordered arrays of the LU-SGS path (agx_lusgs.hpp)
   const agx_bc_surface* surf; // boundaryConditions      boundaryConditions.hpp:231
   int nsurf, nsurf_i, nsurf_j, nsurf_k;
+  // per side (surface type 1..6): 0 no connection BC on it, 1 all of it is
+  // interblock / periodic, 2 mixed (look the cell up in `surf`)
+  int side_conn[6];
   __host__ __device__ long idx(int i, int j, int k) const {
     return (long)(k + ng) * sxy + (long)(j + ng) * sx + (i + ioff);
   }
@@ -1231,7 +1234,8 @@ k_visc_march(BlockDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
 // ---------------------------------------------------------------------------
 // boundary conditions
 // boundaryConditions::GetBCSurface boundaryConditions.cpp:109-170
-__device__ inline const agx_bc_surface* get_bc_surface(const BlockDev& b, int i,
+template <class B>
+__device__ inline const agx_bc_surface* get_bc_surface(const B& b, int i,
                                                        int j, int k, int surf) {
   if (surf <= 2) {
     for (int n = 0; n < b.nsurf_i; ++n) {
@@ -1254,8 +1258,14 @@ __device__ inline const agx_bc_surface* get_bc_surface(const BlockDev& b, int i,
   }
   return nullptr;
 }
-__device__ __forceinline__ bool bc_is_connection(const BlockDev& b, int i, int j,
+template <class B>
+__device__ __forceinline__ bool bc_is_connection(const B& b, int i, int j,
                                                  int k, int surf) {
+  // the common cases (a side without any / made only of connection surfaces) are
+  // answered from the kernel arguments: the surface list sits in global memory
+  // and walking it is a chain of dependent loads
+  const int sc = b.side_conn[surf - 1];
+  if (sc != 2) return sc == 1;
   const agx_bc_surface* s = get_bc_surface(b, i, j, k, surf);
   return s && (s->bc_type == AGX_BC_INTERBLOCK || s->bc_type == AGX_BC_PERIODIC);
 }
@@ -1392,7 +1402,7 @@ __global__ void k_bc_edges(BlockDev b, GasDev g, int viscous, int* err) {
 // halo exchange: multiArray3d.hpp:790-918 (SwapSliceLocal / InsertSlice) with
 // index maps precomputed on the host from GetSwapLoc
 // (boundaryConditions.cpp:3006-3181).  buf is [n][ncomp].
-struct Planes5 { double* p[AGX_NEQ]; };
+struct Planes5 { double* p[AGX_NEQ]; long stride; };   // element q of plane e: p[e][q * stride]
 // both sides of one local connection in one launch (blockIdx.y = side)
 struct HaloSide { Planes5 a; const long* map; long n; double* buf; };
 __global__ void k_halo_gather2(HaloSide s0, HaloSide s1) {
@@ -1401,7 +1411,7 @@ __global__ void k_halo_gather2(HaloSide s0, HaloSide s1) {
   if (t >= s.n) return;
   const long q = s.map[t];
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) s.buf[e * s.n + t] = s.a.p[e][q];
+  for (int e = 0; e < AGX_NEQ; ++e) s.buf[e * s.n + t] = s.a.p[e][q * s.a.stride];
 }
 __global__ void k_halo_scatter2(HaloSide s0, HaloSide s1) {
   const HaloSide& s = blockIdx.y == 0 ? s0 : s1;
@@ -1409,7 +1419,7 @@ __global__ void k_halo_scatter2(HaloSide s0, HaloSide s1) {
   if (t >= s.n) return;
   const long q = s.map[t];
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) s.a.p[e][q] = s.buf[e * s.n + t];
+  for (int e = 0; e < AGX_NEQ; ++e) s.a.p[e][q * s.a.stride] = s.buf[e * s.n + t];
 }
 __global__ void k_halo_gather(Planes5 a, const long* __restrict__ src, long n,
                               double* __restrict__ buf) {
@@ -1417,7 +1427,7 @@ __global__ void k_halo_gather(Planes5 a, const long* __restrict__ src, long n,
   if (t >= n) return;
   const long q = src[t];
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) buf[e * n + t] = a.p[e][q];
+  for (int e = 0; e < AGX_NEQ; ++e) buf[e * n + t] = a.p[e][q * a.stride];
 }
 __global__ void k_halo_scatter(Planes5 a, const long* __restrict__ dst, long n,
                                const double* __restrict__ buf) {
@@ -1425,7 +1435,7 @@ __global__ void k_halo_scatter(Planes5 a, const long* __restrict__ dst, long n,
   if (t >= n) return;
   const long q = dst[t];
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) a.p[e][q] = buf[e * n + t];
+  for (int e = 0; e < AGX_NEQ; ++e) a.p[e][q * a.stride] = buf[e * n + t];
 }
 
 // ---------------------------------------------------------------------------
@@ -1435,19 +1445,12 @@ __global__ void k_halo_scatter(Planes5 a, const long* __restrict__ dst, long n,
 // equation and the signed max residual with its first (k,j,i,eqn) location;
 // a second kernel folds the partials in a fixed order (reproducible).
 
-__device__ __forceinline__ void norm_block_reduce(const double* r, long lin0,
-                                                  bool active,
-                                                  NormPartial* out) {
-  __shared__ double sh[AGX_NEQ + 1][4];
-  __shared__ long long shl[4];
-  double v[AGX_NEQ];
-  double vmax = -1.0e300;
-  long long lin = 0x7fffffffffffffffLL;
-#pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) {
-    v[e] = active ? r[e] * r[e] : 0.0;
-    if (active && r[e] > vmax) { vmax = r[e]; lin = lin0 + e; }
-  }
+// workgroup fold of per-thread partial norms (sum of r^2 per equation, signed
+// max with its first location); thread 0 writes the result
+__device__ __forceinline__ void norm_block_fold(double* v, double vmax, long long lin,
+                                                NormPartial* out) {
+  __shared__ double sh[AGX_NEQ + 1][16];
+  __shared__ long long shl[16];
   for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) v[e] += __shfl_down(v[e], off, 64);
@@ -1482,6 +1485,19 @@ __device__ __forceinline__ void norm_block_reduce(const double* r, long lin0,
       }
     *out = p;
   }
+}
+__device__ __forceinline__ void norm_block_reduce(const double* r, long lin0,
+                                                  bool active,
+                                                  NormPartial* out) {
+  double v[AGX_NEQ];
+  double vmax = -1.0e300;
+  long long lin = 0x7fffffffffffffffLL;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    v[e] = active ? r[e] * r[e] : 0.0;
+    if (active && r[e] > vmax) { vmax = r[e]; lin = lin0 + e; }
+  }
+  norm_block_fold(v, vmax, lin, out);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1712,534 +1728,9 @@ __global__ void k_lusgs_plane(BlockDev b, GasDev g, SolverDev sp, int plane, int
   store5(b.x, q, acc);
 }
 
-// ---------------------------------------------------------------------------
-// LU-SGS as a two-level wavefront (production form of the sweeps).
-//
-// The block is cut into bricks of LBI x 8 x 8 cells.  Bricks on a coarse
-// hyperplane BI+BJ+BK = P are independent and form one launch; inside a brick
-// ONE WAVE walks the fine hyperplanes li+lj+lk = s.  Lane (lj, lk) owns the
-// i-line (., lj, lk) of the brick and meets its cells in order, so
-//   * the i-neighbour on the sweep side is the lane's own previous cell
-//     (registers),
-//   * the j / k neighbours are what lanes -+1 / -+8 finished in the previous
-//     step (wave shuffles),
-//   * only neighbours outside the brick are read from memory, and those were
-//     completed by earlier launches,
-// i.e. there is no memory round trip on the dependency chain.  Any topological
-// order of the dependency graph gives the same x as the reference's global
-// hyperplane order (HyperplaneReorder utility.cpp:377-398), so results are
-// unchanged.
-//
-// Cells that are in flight together always lie in different grid rows, so SoA
-// planes would cost one 128-byte line per 8-byte value.  For the sweeps the
-// per-cell data is therefore gathered into two 128-byte records per cell
-// (k_lusgs_pack / k_lusgs_geo), read whole by the owning lane:
-//   rec_dyn[q] = { x[5], 1/A, state[5], b[5] }      b = right-hand side
-//   rec_geo[q] = { centre[3], areaI[4], areaJ[4], areaK[4], mu }  lower faces
-// Follows lusgs::LUSGS_Forward linearSolver.cpp:341-383 / LUSGS_Backward
-// :385-428 with procBlock::ImplicitLower / ImplicitUpper procBlock.cpp:1056-1163.
-constexpr int LREC = 16;
-__device__ __forceinline__ void lusgs_ld(const double* p, int first, int count2,
-                                         double* out) {
-  // count2 aligned double2 loads starting at double index `first` (even)
-  const double2* v = reinterpret_cast<const double2*>(p + first);
-#pragma unroll
-  for (int m = 0; m < count2; ++m) {
-    const double2 t = v[m];
-    out[2 * m] = t.x;
-    out[2 * m + 1] = t.y;
-  }
-}
-
-__global__ void __launch_bounds__(256) k_lusgs_geo(BlockDev b) {
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= b.nplane) return;
-  double* r = b.rec_geo + q * LREC;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    r[d] = b.cen[d][q];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) r[3 + 4 * d + c] = b.fa[d][c][q];
-  }
-  r[15] = 0.0;
-}
-
-// SoA -> records before a half sweep (all padded cells: ghost cells carry the
-// state and the exchanged x of the neighbouring block)
-__global__ void __launch_bounds__(256) k_lusgs_pack(BlockDev b, GasDev g, SolverDev sp) {
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= b.nplane) return;
-  const int k = (int)(q / b.sxy) - b.ng;
-  const long rem = q % b.sxy;
-  const int j = (int)(rem / b.sx) - b.ng, i = (int)(rem % b.sx) - b.ioff;
-  const bool phys = i >= 0 && i < b.ni && j >= 0 && j < b.nj && k >= 0 && k < b.nk;
-  double r[LREC];
-  load5(b.x, q, r);
-  load5(b.state, q, r + 6);
-  r[5] = 0.0;
-#pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) r[11 + e] = 0.0;
-  if (phys) {
-    r[5] = b.ainv[q];
-    rhs_b(b, g, sp, q, r + 11);
-  }
-  double2* o = reinterpret_cast<double2*>(b.rec_dyn + q * LREC);
-#pragma unroll
-  for (int m = 0; m < LREC / 2; ++m) o[m] = make_double2(r[2 * m], r[2 * m + 1]);
-  // laminar viscosity of the cell (UpdateAuxillaryVariables procBlock.cpp:6171)
-  // rides in the spare slot of the geometry record
-  if (sp.viscous) b.rec_geo[q * LREC + 15] = r[6] > 0.0 ? viscosity(g, temperature(g, r + 6)) : 0.0;
-}
-// records -> SoA x after a half sweep
-__global__ void __launch_bounds__(256) k_lusgs_unpack(BlockDev b) {
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= b.nplane) return;
-  double x[6];
-  lusgs_ld(b.rec_dyn + q * LREC, 0, 3, x);
-  store5(b.x, q, x);
-}
-
-struct LusgsNbr { double x[AGX_NEQ], s[AGX_NEQ], c[3], mu, a[4]; };   // a: backward only
-struct LusgsDone { double x[AGX_NEQ], s[AGX_NEQ], c[3], mu, area[3][4]; };
-
-template <bool FORWARD>
-__device__ __forceinline__ void lusgs_load_nbr(const BlockDev& b, bool viscous, long q,
-                                               int d, LusgsNbr& n) {
-  double t[12];
-  lusgs_ld(b.rec_dyn + q * LREC, 0, 6, t);
-#pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) { n.x[e] = t[e]; n.s[e] = t[6 + e]; }
-  const double* gr = b.rec_geo + q * LREC;
-  n.mu = 0.0;
-  if (viscous) { n.c[0] = gr[0]; n.c[1] = gr[1]; n.c[2] = gr[2]; n.mu = gr[15]; }
-  if (!FORWARD) {
-    // the face between the two cells is the neighbour's lower face
-#pragma unroll
-    for (int c = 0; c < 4; ++c) n.a[c] = gr[3 + 4 * d + c];
-  }
-}
-// one neighbour's contribution; `cen` is the own cell's centre, `lower` says on
-// which side the neighbour sits (face `area` is the one between the two cells)
-__device__ __forceinline__ void lusgs_nbr_term(const GasDev& g, const SolverDev& sp,
-                                               const double* nx, const double* ns,
-                                               const double* nc, double mu,
-                                               const double* area,
-                                               const double* cen, bool lower,
-                                               double sign, bool use, double* acc) {
-  // branch-free on purpose: the three neighbour terms of a cell are independent
-  // instruction chains, and a lone wave per SIMD needs them in one basic block to
-  // overlap their latencies; `use` only selects at the end (inputs of an unused
-  // neighbour may be anything)
-  double dist = 1.0, od[AGX_NEQ];
-  if (sp.viscous) {
-    // ProjC2CDist procBlock.cpp:6316-6342: (upper centre - lower centre) . n
-    const double sg = lower ? 1.0 : -1.0;
-    const double v[3] = {sg * (cen[0] - nc[0]), sg * (cen[1] - nc[1]),
-                         sg * (cen[2] - nc[2])};
-    dist = dot3(v, area);
-  }
-  off_diagonal(g, sp.viscous, ns, nx, area, mu, dist, lower, od);
-#pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) acc[e] += use ? sign * od[e] : 0.0;
-}
-
-// everything one cell of the sweep reads from memory, fetched ONE STEP AHEAD so
-// that no load sits on the step-to-step dependency chain
-struct LusgsCell {
-  double x[AGX_NEQ], ainv, s[AGX_NEQ], rb[AGX_NEQ];   // rec_dyn
-  double c[3], area[3][4], mu;                         // rec_geo
-  LusgsNbr ob[3];          // sweep-side neighbours that lie outside the brick
-  int use, inside;         // bit d: neighbour d counts / comes from inside the brick
-};
-
-// direction D of lusgs_fetch (a template so that every struct member is
-// addressed with a compile-time index and stays in registers)
-template <bool FORWARD, int D, bool PIPE = false>
-__device__ __forceinline__ void lusgs_fetch_dir(const BlockDev& b, const SolverDev& sp,
-                                                long q, int i, int j, int k, int lcd,
-                                                int lextd, LusgsCell& c) {
-  const int ccd = D == 0 ? i : (D == 1 ? j : k);
-  const int nnd = D == 0 ? b.ni : (D == 1 ? b.nj : b.nk);
-  const long strd = D == 0 ? 1 : (D == 1 ? b.sx : b.sxy);
-  const bool inside = FORWARD ? lcd > 0 : (lcd < lextd - 1 && ccd < nnd - 1);
-  const bool use = inside ||
-      (FORWARD ? (ccd > 0 || bc_is_connection(b, i, j, k, 2 * D + 1))
-               : (ccd < nnd - 1 ||
-                  bc_is_connection(b, i + (D == 0), j + (D == 1), k + (D == 2), 2 * D + 2)));
-  if (inside) c.inside |= 1 << D;
-  if (use) c.use |= 1 << D;
-  if (use && !inside) {
-    const long qn = q + (FORWARD ? -strd : strd);
-    lusgs_load_nbr<FORWARD>(b, sp.viscous, qn, D, c.ob[D]);
-    if (PIPE) {
-      // the neighbouring brick wrote this x earlier in the SAME launch (possibly
-      // on another XCD): read it with agent-scope loads, after the progress check
-#pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e)
-        c.ob[D].x[e] = __hip_atomic_load(b.rec_dyn + qn * LREC + e, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-template <bool FORWARD, bool PIPE = false>
-__device__ __forceinline__ void lusgs_fetch(const BlockDev& b, const SolverDev& sp,
-                                            int i0, int bi, int li, int lj, int lk, int j,
-                                            int k, int full, LusgsCell& c) {
-  const int i = i0 + li;
-  const long q = b.idx(i, j, k);
-  double t[LREC];
-  // a lone wave pays ~200 cycles per scattered 16-byte-per-lane load, so only
-  // the part of the record this half sweep uses is read: {1/A, state, b} going
-  // forward, {x, 1/A, state} going back (everything when both triangles count)
-  if (full) {
-    lusgs_ld(b.rec_dyn + q * LREC, 0, 8, t);
-  } else if (FORWARD) {
-    lusgs_ld(b.rec_dyn + q * LREC, 4, 6, t + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) t[e] = 0.0;
-  } else {
-    lusgs_ld(b.rec_dyn + q * LREC, 0, 6, t);
-#pragma unroll
-    for (int e = 12; e < LREC; ++e) t[e] = 0.0;
-  }
-#pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) { c.x[e] = t[e]; c.s[e] = t[6 + e]; c.rb[e] = t[11 + e]; }
-  c.ainv = t[5];
-  lusgs_ld(b.rec_geo + q * LREC, 0, 8, t);
-  c.c[0] = t[0]; c.c[1] = t[1]; c.c[2] = t[2];
-  c.mu = t[15];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    c.area[0][m] = t[3 + m]; c.area[1][m] = t[7 + m]; c.area[2][m] = t[11 + m];
-  }
-  c.use = 0; c.inside = 0;
-  lusgs_fetch_dir<FORWARD, 0, PIPE>(b, sp, q, i, j, k, li, bi, c);
-  lusgs_fetch_dir<FORWARD, 1, PIPE>(b, sp, q, i, j, k, lj, 8, c);
-  lusgs_fetch_dir<FORWARD, 2, PIPE>(b, sp, q, i, j, k, lk, 8, c);
-}
-
-// the triangle opposite to the sweep direction (matrixSweeps > 1 only), values
-// of the previous sweep read in place
-template <bool FORWARD, int D>
-__device__ __forceinline__ void lusgs_other_dir(const BlockDev& b, const GasDev& g,
-                                                const SolverDev& sp, long q, int i, int j,
-                                                int k, const double* own_area,
-                                                const double* cen, double* acc) {
-  const int ccd = D == 0 ? i : (D == 1 ? j : k);
-  const int nnd = D == 0 ? b.ni : (D == 1 ? b.nj : b.nk);
-  const long strd = D == 0 ? 1 : (D == 1 ? b.sx : b.sxy);
-  const bool use = !FORWARD
-      ? (ccd > 0 || bc_is_connection(b, i, j, k, 2 * D + 1))
-      : (ccd < nnd - 1 ||
-         bc_is_connection(b, i + (D == 0), j + (D == 1), k + (D == 2), 2 * D + 2));
-  if (!use) return;
-  LusgsNbr nb;
-  // neighbour on the far side: above for the forward sweep (its lower face is the
-  // shared one), below for the backward sweep (the own lower face is shared)
-  if (FORWARD) lusgs_load_nbr<false>(b, sp.viscous, q + strd, D, nb);
-  else lusgs_load_nbr<true>(b, sp.viscous, q - strd, D, nb);
-  lusgs_nbr_term(g, sp, nb.x, nb.s, nb.c, nb.mu, FORWARD ? nb.a : own_area, cen, !FORWARD,
-                 !FORWARD ? 1.0 : -1.0, true, acc);
-}
-
-// Per-step hand-off between bricks of one launch (k_lusgs_pipe): flags[brick] =
-// epoch * 256 + number of fine steps whose x is visible.  A successor brick needs
-// the face cells of its predecessor eight steps after the predecessor formed
-// them, so it can run eight steps behind instead of a whole brick behind.
-struct LusgsStepSync {
-  int* flags;
-  int* err;
-  int epoch, spin_limit;
-  int self;            // own brick id
-  int pre[3];          // predecessor brick ids on the sweep side, -1: none
-  int nsp[3];          // their number of fine steps
-};
-
-// one brick, one wave
-template <bool FORWARD, int LBI, bool PIPE = false>
-__device__ __forceinline__ bool lusgs_brick_body(const BlockDev& b, const GasDev& g,
-                                                 const SolverDev& sp, int full, int BI,
-                                                 int BJ, int BK,
-                                                 const LusgsStepSync* ss = nullptr) {
-  const int lane = threadIdx.x;
-  const int lj = lane & 7, lk = lane >> 3;
-  const int i0 = BI * LBI, j = BJ * 8 + lj, k = BK * 8 + lk;
-  const int bi = min(LBI, b.ni - i0);
-  const bool line = j < b.nj && k < b.nk;
-  const int nsteps = bi + min(8, b.nj - BJ * 8) + min(8, b.nk - BK * 8) - 2;
-  // fine-plane position of this lane's cell at step t
-  auto li_at = [&](int t) { return (FORWARD ? t : nsteps - 1 - t) - lj - lk; };
-  auto act_at = [&](int t) { const int l = li_at(t); return line && l >= 0 && l < bi; };
-  LusgsDone prev;                              // the cell this lane finished last
-#pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) { prev.x[e] = 0.0; prev.s[e] = 1.0; }
-  prev.mu = 0.0;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    prev.c[d] = 0.0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) prev.area[d][m] = 0.0;
-  }
-  // two cell buffers used alternately: one is consumed while the other is filled
-  // PIPE: the steps of the predecessors this brick's step t depends on
-  bool ok = true;
-  int pg[3] = {0, 0, 0};           // last progress value seen per predecessor
-  auto need = [&](int d, int t) {
-    // forward: the predecessor (always a full brick) forms the needed face cell
-    // ext steps after the step index this brick uses it at; backward the same
-    // counted from the other end of both step ranges
-    const int ext = d == 0 ? LBI : 8;
-    const int v = t + ext + (FORWARD ? 0 : ss->nsp[d] - nsteps);
-    return ss->epoch * 256 + max(0, min(v, ss->nsp[d]));
-  };
-  auto poll = [&](int d) {
-    return __hip_atomic_load(ss->flags + ss->pre[d], __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto wait_for = [&](int t) {      // until every predecessor covers step t
-    if (!PIPE || t >= nsteps) return;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      if (ss->pre[d] < 0 || !ok) continue;
-      int spins = 0;
-      while (pg[d] < need(d, t)) {
-        pg[d] = poll(d);
-        if (pg[d] >= need(d, t)) break;
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > ss->spin_limit ||
-            __hip_atomic_load(ss->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          ok = false;
-          break;
-        }
-      }
-    }
-  };
-  auto publish = [&](int done) {    // steps 0 .. done-1 of this brick are visible
-    if (!PIPE) return;
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the x stores have landed
-    __hip_atomic_store(ss->flags + ss->self, ss->epoch * 256 + done, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  };
-  LusgsCell ca, cb;
-  wait_for(0);
-  if (!ok) return false;
-  if (act_at(0)) lusgs_fetch<FORWARD, PIPE>(b, sp, i0, bi, li_at(0), lj, lk, j, k, full, ca);
-  auto step = [&](int t, const LusgsCell& cur, LusgsCell& nxt) {
-    const int li = li_at(t);
-    const bool act = act_at(t);
-    if (PIPE) {
-      wait_for(t + 1);
-      if (!ok) return;
-      // refresh the progress values early for the step after next
-#pragma unroll
-      for (int d = 0; d < 3; ++d)
-        if (ss->pre[d] >= 0) pg[d] = poll(d);
-    }
-    if (t + 1 < nsteps && act_at(t + 1))
-      lusgs_fetch<FORWARD, PIPE>(b, sp, i0, bi, li_at(t + 1), lj, lk, j, k, full, nxt);
-    // what the neighbouring lanes finished in the previous step
-    double jx[AGX_NEQ], js[AGX_NEQ], jc[3], ja[4], kx[AGX_NEQ], ks[AGX_NEQ], kc[3], ka[4];
-#pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) {
-      jx[e] = FORWARD ? __shfl_up(prev.x[e], 1, 64) : __shfl_down(prev.x[e], 1, 64);
-      js[e] = FORWARD ? __shfl_up(prev.s[e], 1, 64) : __shfl_down(prev.s[e], 1, 64);
-      kx[e] = FORWARD ? __shfl_up(prev.x[e], 8, 64) : __shfl_down(prev.x[e], 8, 64);
-      ks[e] = FORWARD ? __shfl_up(prev.s[e], 8, 64) : __shfl_down(prev.s[e], 8, 64);
-    }
-    double jmu = 0.0, kmu = 0.0;
-    if (sp.viscous) {
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        jc[d] = FORWARD ? __shfl_up(prev.c[d], 1, 64) : __shfl_down(prev.c[d], 1, 64);
-        kc[d] = FORWARD ? __shfl_up(prev.c[d], 8, 64) : __shfl_down(prev.c[d], 8, 64);
-      }
-      jmu = FORWARD ? __shfl_up(prev.mu, 1, 64) : __shfl_down(prev.mu, 1, 64);
-      kmu = FORWARD ? __shfl_up(prev.mu, 8, 64) : __shfl_down(prev.mu, 8, 64);
-    }
-    if (!FORWARD) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        ja[m] = __shfl_down(prev.area[1][m], 1, 64);
-        ka[m] = __shfl_down(prev.area[2][m], 8, 64);
-      }
-    }
-    const int i = i0 + li;
-    const long q = b.idx(i0 + max(0, min(li, bi - 1)), min(j, b.nj - 1), min(k, b.nk - 1));
-    double xn[AGX_NEQ] = {0, 0, 0, 0, 0};
-    if (act) {
-    double acc[AGX_NEQ] = {0, 0, 0, 0, 0};
-    const double sgn = FORWARD ? 1.0 : -1.0;
-    // sweep side (L for the forward sweep, U for the backward sweep); the face
-    // is the own lower face (forward) or the neighbour's lower face (backward)
-    {
-      const bool in = cur.inside & 1;
-      double nx[AGX_NEQ], ns[AGX_NEQ], nc[3], na[4];
-#pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e) {
-        nx[e] = in ? prev.x[e] : cur.ob[0].x[e];
-        ns[e] = in ? prev.s[e] : cur.ob[0].s[e];
-      }
-#pragma unroll
-      for (int d = 0; d < 3; ++d) nc[d] = in ? prev.c[d] : cur.ob[0].c[d];
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        na[m] = FORWARD ? cur.area[0][m] : (in ? prev.area[0][m] : cur.ob[0].a[m]);
-      lusgs_nbr_term(g, sp, nx, ns, nc, in ? prev.mu : cur.ob[0].mu, na, cur.c, FORWARD,
-                     sgn, cur.use & 1, acc);
-    }
-    {
-      const bool in = cur.inside & 2;
-      double nx[AGX_NEQ], ns[AGX_NEQ], nc[3], na[4];
-#pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e) {
-        nx[e] = in ? jx[e] : cur.ob[1].x[e];
-        ns[e] = in ? js[e] : cur.ob[1].s[e];
-      }
-#pragma unroll
-      for (int d = 0; d < 3; ++d) nc[d] = in ? jc[d] : cur.ob[1].c[d];
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        na[m] = FORWARD ? cur.area[1][m] : (in ? ja[m] : cur.ob[1].a[m]);
-      lusgs_nbr_term(g, sp, nx, ns, nc, in ? jmu : cur.ob[1].mu, na, cur.c, FORWARD, sgn,
-                     cur.use & 2, acc);
-    }
-    {
-      const bool in = cur.inside & 4;
-      double nx[AGX_NEQ], ns[AGX_NEQ], nc[3], na[4];
-#pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e) {
-        nx[e] = in ? kx[e] : cur.ob[2].x[e];
-        ns[e] = in ? ks[e] : cur.ob[2].s[e];
-      }
-#pragma unroll
-      for (int d = 0; d < 3; ++d) nc[d] = in ? kc[d] : cur.ob[2].c[d];
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        na[m] = FORWARD ? cur.area[2][m] : (in ? ka[m] : cur.ob[2].a[m]);
-      lusgs_nbr_term(g, sp, nx, ns, nc, in ? kmu : cur.ob[2].mu, na, cur.c, FORWARD, sgn,
-                     cur.use & 4, acc);
-    }
-    if (full || FORWARD) {
-      if (full) {
-        lusgs_other_dir<FORWARD, 0>(b, g, sp, q, i, j, k, cur.area[0], cur.c, acc);
-        lusgs_other_dir<FORWARD, 1>(b, g, sp, q, i, j, k, cur.area[1], cur.c, acc);
-        lusgs_other_dir<FORWARD, 2>(b, g, sp, q, i, j, k, cur.area[2], cur.c, acc);
-      }
-#pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e) xn[e] = (cur.rb[e] + acc[e]) * cur.ainv;
-    } else {
-#pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e) xn[e] = cur.x[e] + acc[e] * cur.ainv;
-    }
-    }
-    // progress is published one step late, between the arithmetic of this step
-    // and its stores: the stores of step t-1 are a whole step old by now and the
-    // prefetch issued at the top of this step has had the arithmetic to land
-    if (PIPE) publish(t);
-    if (!act) return;
-    double* r = b.rec_dyn + q * LREC;
-    if (PIPE) {
-#pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e)
-        __hip_atomic_store(r + e, xn[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      reinterpret_cast<double2*>(r)[0] = make_double2(xn[0], xn[1]);
-      reinterpret_cast<double2*>(r)[1] = make_double2(xn[2], xn[3]);
-      r[4] = xn[4];
-    }
-#pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) { prev.x[e] = xn[e]; prev.s[e] = cur.s[e]; }
-    prev.mu = cur.mu;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      prev.c[d] = cur.c[d];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) prev.area[d][m] = cur.area[d][m];
-    }
-  };
-  for (int t = 0; t < nsteps; t += 2) {
-    step(t, ca, cb);
-    if (!ok) return false;
-    if (t + 1 < nsteps) {
-      step(t + 1, cb, ca);
-      if (!ok) return false;
-    }
-  }
-  publish(nsteps);
-  return true;
-}
-
-// (a) one launch per coarse hyperplane (AGX_LUSGS=brick): every wave takes the
-//     brick (BJ, BK) of plane `cplane`
-template <bool FORWARD, int LBI>
-__global__ void __launch_bounds__(256)
-k_lusgs_brick(BlockDev b, GasDev g, SolverDev sp, int cplane, int full, int nbi, int nbj,
-              int nbk) {
-  const int slot = blockIdx.x * blockDim.y + threadIdx.y;   // wave-uniform
-  const int BJ = slot % nbj, BK = slot / nbj;
-  if (BK >= nbk) return;
-  const int BI = cplane - BJ - BK;
-  if (BI < 0 || BI >= nbi) return;
-  lusgs_brick_body<FORWARD, LBI>(b, g, sp, full, BI, BJ, BK);
-}
-
-// (b) ONE launch per half sweep (default): persistent waves draw bricks from a
-//     ticket counter in coarse-plane order; a brick publishes after every fine
-//     step how far it is, and a successor only needs its predecessors to be eight
-//     steps ahead (LusgsStepSync), so the dependent chain is the 766 fine
-//     hyperplanes of the block again instead of 94 bricks x 22 steps.
-//     Progress: a ticket is only ever held by a running wave and every
-//     predecessor of a brick has a smaller ticket, so the wave holding the
-//     smallest unfinished ticket never waits -- no dependence on dispatch order.
-//     Every wave leaves the loop when the tickets run out; a wave that spins
-//     longer than `spin_limit` polls raises *err and all waves drain.
-//     Hand-off is per fine STEP (LusgsStepSync): x is stored with agent-scope
-//     (write-through) stores, the brick's progress counter follows after
-//     vmcnt(0), and consumers read counter and x with agent-scope loads.
-struct LusgsPipe {
-  const int* order;     // ticket -> packed brick id (BI + nbi * (BJ + nbj * BK))
-  int* flags;           // per brick: epoch of the half sweep that completed it
-  int* ticket;
-  int* err;
-  int total, epoch, spin_limit;
-};
-template <bool FORWARD, int LBI>
-__global__ void __launch_bounds__(256)
-k_lusgs_pipe(BlockDev b, GasDev g, SolverDev sp, int full, int nbi, int nbj, int nbk,
-             LusgsPipe pp) {
-  // Every lane executes the same scalar protocol on the same addresses (the
-  // hardware merges them): no lane-0-only control flow for the compiler to
-  // restructure, and the loop exits are uniform by construction.
-  const int lane = threadIdx.x;
-  for (;;) {
-    int t = atomicAdd(pp.ticket, lane == 0 ? 1 : 0);
-    t = __shfl(t, 0, 64);
-    if (t >= pp.total) break;
-    int id = pp.order[FORWARD ? t : pp.total - 1 - t];
-    id = __builtin_amdgcn_readfirstlane(id);
-    const int BI = id % nbi, BJ = (id / nbi) % nbj, BK = id / (nbi * nbj);
-    // predecessors on the sweep side and how many fine steps each of them has
-    const int sd = FORWARD ? -1 : 1;
-    const int pc[3][3] = {{BI + sd, BJ, BK}, {BI, BJ + sd, BK}, {BI, BJ, BK + sd}};
-    const int nb3[3] = {nbi, nbj, nbk};
-    LusgsStepSync ss;
-    ss.flags = pp.flags; ss.err = pp.err; ss.epoch = pp.epoch; ss.spin_limit = pp.spin_limit;
-    ss.self = id;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const bool ex = pc[d][d] >= 0 && pc[d][d] < nb3[d];
-      ss.pre[d] = ex ? pc[d][0] + nbi * (pc[d][1] + nbj * pc[d][2]) : -1;
-      ss.nsp[d] = ex ? min(LBI, b.ni - pc[d][0] * LBI) + min(8, b.nj - pc[d][1] * 8) +
-                           min(8, b.nk - pc[d][2] * 8) - 2
-                     : 0;
-    }
-    if (!lusgs_brick_body<FORWARD, LBI, true>(b, g, sp, full, BI, BJ, BK, &ss)) {
-      __hip_atomic_store(pp.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
-    }
-  }
-}
+}  // namespace agx
+#include "agx_lusgs_kernels.hpp"
+namespace agx {
 
 // dplur::DPLUR linearSolver.cpp:473-507 (point Jacobi on the copied xold)
 __global__ void __launch_bounds__(256)

@@ -107,20 +107,46 @@ def test_kernel_variants_agree(agx):
 
 
 @pytest.mark.gpu
-def test_lusgs_sweep_forms_agree(agx):
-    """Brick wavefront (default), single-launch pipelined bricks and the
-    launch-per-hyperplane form order the same dependency graph differently and
-    must give the same update."""
+@pytest.mark.parametrize("sweeps", [1, 2])
+def test_lusgs_sweep_forms_agree(agx, sweeps):
+    """The pipelined k-plane sweep on the diagonal-ordered arrays (default) and
+    the launch-per-hyperplane form on the SoA planes order the same dependency
+    graph differently and must give the same update (sweeps = 2 also runs the
+    both-triangle branches)."""
     wall = {3: ("viscousWall", 2), 1: ("characteristic", 1),
             2: ("characteristic", 1), 4: ("characteristic", 1)}
     case = synthetic.single_block_case(n=(21, 19, 17), stretch=1.1, bcs=wall,
                                        equation_set="navierStokes",
                                        time_integration="implicitEuler",
+                                       matrix_solver="lusgs", matrix_sweeps=sweeps,
+                                       cfl=5.0)
+    ref = _run_with_env(agx, case, 2, {"AGX_LUSGS": "kp"})
+    got = _run_with_env(agx, case, 2, {"AGX_LUSGS": "plane"})
+    assert rel_err(got, ref) < 1e-12
+
+
+@pytest.mark.gpu
+def test_lusgs_spin_limit_error_path(agx, oracle):
+    """A k-plane that waits longer than AGX_SPIN_LIMIT polls for its predecessor
+    raises the error flag, the grid drains, agx_iterate returns the error -- and a
+    fresh context works again (the limit is read when the context is created)."""
+    case = synthetic.single_block_case(n=(40, 36, 12), stretch=1.1,
+                                       time_integration="implicitEuler",
                                        matrix_solver="lusgs", cfl=5.0)
-    ref = _run_with_env(agx, case, 2, {"AGX_LUSGS": "pipe", "AGX_SPIN_LIMIT": "200000"})
-    for kind in ("plane", "brick"):
-        got = _run_with_env(agx, case, 2, {"AGX_LUSGS": kind})
-        assert rel_err(got, ref) < 1e-12, kind
+    old = os.environ.get("AGX_SPIN_LIMIT")
+    os.environ["AGX_SPIN_LIMIT"] = "1"
+    try:
+        s = Solver(agx, case)
+    finally:
+        if old is None:
+            os.environ.pop("AGX_SPIN_LIMIT", None)
+        else:
+            os.environ["AGX_SPIN_LIMIT"] = old
+    with pytest.raises(RuntimeError, match="spin limit"):
+        for nn in range(20):      # one poll is not always too few: repeat
+            s.step(nn)
+    s.close()
+    _close(*run_pair(agx, oracle, case, 2))
 
 
 @pytest.mark.gpu
