@@ -437,18 +437,20 @@ bool use_d2(const agx_ctx* c) {
 template <bool FWD, bool FULL, bool CONN, int CH>
 int lusgs_kp_launch(agx_ctx* c, Block& blk) {
   const BlockDev& b = blk.d;
+  // one progress counter per k-plane, each on a cache line of its own, + the ticket
+  const size_t kp_ints = ((size_t)b.nk + 1) * KP_FLAG_STRIDE;
   if (!blk.kp_mem) {
-    HIPCHK(hipMalloc((void**)&blk.kp_mem, sizeof(int) * ((size_t)b.nk + 1)));
-    HIPCHK(hipMemsetAsync(blk.kp_mem, 0, sizeof(int) * ((size_t)b.nk + 1), c->stream));
+    HIPCHK(hipMalloc((void**)&blk.kp_mem, sizeof(int) * kp_ints));
+    HIPCHK(hipMemsetAsync(blk.kp_mem, 0, sizeof(int) * kp_ints, c->stream));
     blk.kp_epoch = 0;
   }
   if (blk.kp_epoch >= 30000) {   // flags hold epoch << 16 | steps: restart before it wraps
-    HIPCHK(hipMemsetAsync(blk.kp_mem, 0, sizeof(int) * ((size_t)b.nk + 1), c->stream));
+    HIPCHK(hipMemsetAsync(blk.kp_mem, 0, sizeof(int) * kp_ints, c->stream));
     blk.kp_epoch = 0;
   }
   KpArgs kp;
   kp.flags = blk.kp_mem;
-  kp.ticket = blk.kp_mem + b.nk;
+  kp.ticket = blk.kp_mem + (size_t)b.nk * KP_FLAG_STRIDE;
   kp.err = c->err_dev;
   kp.epoch = ++blk.kp_epoch;
   kp.spin_limit = c->spin_limit;

@@ -297,6 +297,15 @@ struct KpCell {   // everything of one cell that does not depend on this launch
 #ifndef KP_DEFER
 #define KP_DEFER 0
 #endif
+// KP_QX_AHEAD: request the k-neighbour's x one step before it is used (costs one
+// more step of distance between the planes)
+#ifndef KP_QX_AHEAD
+#define KP_QX_AHEAD 0
+#endif
+#ifndef KP_SLEEP
+#define KP_SLEEP 2
+#endif
+constexpr int KP_FLAG_STRIDE = 32;   // ints: one 128-byte line per progress counter
 template <bool FWD, bool FULL, bool CONN, int CH>
 __global__ void __launch_bounds__(256)
 k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
@@ -315,8 +324,9 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
   auto wait_for = [&](int kq, int steps) {    // thread 0 only
     const int need = ebase + steps;
     int spins = 0;
-    while (__hip_atomic_load(kp.flags + kq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_load(kp.flags + kq * KP_FLAG_STRIDE, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(KP_SLEEP);
       if (++spins > kp.spin_limit ||
           __hip_atomic_load(kp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         s_ok = 0;
@@ -461,9 +471,10 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
     for (int t = -1; t <= nsteps; ++t) {
       KP_STAMP(0);
       if (KP_DEFER) store_x();
+      if (!KP_QX_AHEAD && t >= 0 && t < nsteps) load_qx(cur, qx);
       if (t + 1 < nsteps) {
         fetch(t + 1, nxt);
-        load_qx(nxt, qxn);
+        if (KP_QX_AHEAD) load_qx(nxt, qxn);
       }
       KP_STAMP(1);
       if (t >= 0 && t < nsteps) {
@@ -477,15 +488,6 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
         if (!c.act) continue;
         const long own = kbase + c.pos;
         double acc[AGX_NEQ] = {0, 0, 0, 0, 0};
-        // the k-neighbour first: nothing of it depends on this step
-        if (k_any) {
-          const double qs5[AGX_NEQ] = {c.qs[0].x, c.qs[0].y, c.qs[1].x, c.qs[1].y, c.qs[2].x};
-          const double qx5[AGX_NEQ] = {qx[m][0].x, qx[m][0].y, qx[m][1].x, qx[m][1].y, qx[m][2].x};
-          KpRec r;
-          kp_build_rec(g, qs5, c.qs[2].y, c.qvf, qx5, r);
-          const bool on = CONN ? (c.use & 4) != 0 : true;
-          kp_term(r, c.f[2].n, on ? c.f[2].a : 0.0, on ? c.f[2].ad : 0.0, true, FWD, acc);
-        }
         // in-plane neighbours: slot of cell j' in the previous diagonal's records
         // is j' - jmin_prev + 1 (clamped: a neighbour outside the block has a zero
         // face area and any finite record will do)
@@ -508,6 +510,15 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
             const bool on = (c.use & (1 << q)) != 0;
             kp_term(r, c.f[q].n, on ? c.f[q].a : 0.0, on ? c.f[q].ad : 0.0, true, FWD, acc);
           }
+        }
+        // the k-neighbour last: its x was requested at the top of this step
+        if (k_any) {
+          const double qs5[AGX_NEQ] = {c.qs[0].x, c.qs[0].y, c.qs[1].x, c.qs[1].y, c.qs[2].x};
+          const double qx5[AGX_NEQ] = {qx[m][0].x, qx[m][0].y, qx[m][1].x, qx[m][1].y, qx[m][2].x};
+          KpRec r;
+          kp_build_rec(g, qs5, c.qs[2].y, c.qvf, qx5, r);
+          const bool on = CONN ? (c.use & 4) != 0 : true;
+          kp_term(r, c.f[2].n, on ? c.f[2].a : 0.0, on ? c.f[2].ad : 0.0, true, FWD, acc);
         }
         const double ainv = c.o[2].y;
         const double ov[AGX_NEQ] = {c.o[0].x, c.o[0].y, c.o[1].x, c.o[1].y, c.o[2].x};
@@ -560,8 +571,12 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) xn[e] = ov[e] + acc[e] * ainv;
         }
-        // hand-over to the next diagonal through LDS; the global store follows at
-        // the top of the next step
+        xst[m][0] = make_double2(xn[0], xn[1]);
+        xst[m][1] = make_double2(xn[2], xn[3]);
+        xst[m][2] = make_double2(xn[4], ainv);
+        pst[m] = (unsigned)c.pos * 16u;
+        if (!KP_DEFER) store_x();     // on its way while the record is formed
+        // hand-over to the next diagonal through LDS
         const double s5[AGX_NEQ] = {c.s[0].x, c.s[0].y, c.s[1].x, c.s[1].y, c.s[2].x};
         KpRec r;
         kp_build_rec(g, s5, c.s[2].y, c.vf, xn, r);
@@ -572,14 +587,9 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
         wp[9 * nsl] = r.p1; wp[10 * nsl] = r.h1;
         wp[11 * nsl] = r.r0; wp[12 * nsl] = r.v0[0]; wp[13 * nsl] = r.v0[1]; wp[14 * nsl] = r.v0[2];
         wp[15 * nsl] = r.p0; wp[16 * nsl] = r.h0; wp[17 * nsl] = r.cs; wp[18 * nsl] = r.vf;
-        xst[m][0] = make_double2(xn[0], xn[1]);
-        xst[m][1] = make_double2(xn[2], xn[3]);
-        xst[m][2] = make_double2(xn[4], ainv);
-        pst[m] = (unsigned)c.pos * 16u;
       }
       jmin_prev = jmin;
       }
-      if (!KP_DEFER) store_x();
       // every wave drains its stores, then the barrier, then ONE lane publishes
       KP_STAMP(2);
       // (the builtin lets the compiler's own scoreboard see the wait, so that it
@@ -588,7 +598,7 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
       __builtin_amdgcn_s_waitcnt(0x0F70);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       KP_STAMP(3);
-      if (tid == 0 && has_pre && t + 2 < nsteps) wait_for(kq, t + 3);
+      if (tid == 0 && has_pre && t + 1 + KP_QX_AHEAD < nsteps) wait_for(kq, t + 2 + KP_QX_AHEAD);
       KP_STAMP(4);
       __syncthreads();
       KP_STAMP(5);
@@ -596,15 +606,17 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
       const int vis = KP_DEFER ? t : min(t + 1, nsteps);   // diagonals whose x has landed
       if (tid == 0 && vis > 0) {
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        __hip_atomic_store(kp.flags + k, ebase + vis, __ATOMIC_RELAXED,
+        __hip_atomic_store(kp.flags + k * KP_FLAG_STRIDE, ebase + vis, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
       }
       if (t + 1 < nsteps) {
 #pragma unroll
         for (int m = 0; m < CH; ++m) {
           cur[m] = nxt[m];
+          if (KP_QX_AHEAD) {
 #pragma unroll
-          for (int h = 0; h < 3; ++h) qx[m][h] = qxn[m][h];
+            for (int h = 0; h < 3; ++h) qx[m][h] = qxn[m][h];
+          }
         }
       }
     }
