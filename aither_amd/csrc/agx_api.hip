@@ -70,7 +70,9 @@ struct Conn {
   long* send_src2 = nullptr;
 };
 
-enum { G_RESID = 0, G_UPDATE = 1, G_BC = 2, G_SWEEP = 3, G_NGROUP = 4 };
+// timing groups of agx_timing_get (include/aither_gfx950.h)
+enum { G_RESID = 0, G_UPDATE = 1, G_BC = 2, G_SWEEP = 3, G_VISC = 4, G_PREPARE = 5,
+       G_MRESID = 6, G_NGROUP = 7 };
 
 }  // namespace
 
@@ -113,8 +115,8 @@ struct agx_ctx {
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   std::vector<std::pair<int, int>> ev_used;   // (group, pool index)
-  double t_ms[G_NGROUP] = {0, 0, 0, 0};
-  long t_n[G_NGROUP] = {0, 0, 0, 0};
+  double t_ms[G_NGROUP] = {};
+  long t_n[G_NGROUP] = {};
 };
 
 namespace {
@@ -1080,7 +1082,7 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
       if (bc_pass(c, true, 1)) return 1;
       if (bc_pass(c, false, 1)) return 1;
     }
-    Timer t(c, G_RESID);
+    Timer t(c, G_VISC);
     for (auto& blk : c->blocks)
       if (c->visc_gather) {
         hipLaunchKernelGGL(k_visc_residual, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
@@ -1105,7 +1107,7 @@ int agx_phase_explicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
 }
 
 int agx_phase_implicit_begin(agx_ctx* c) {
-  Timer t(c, G_SWEEP);
+  Timer t(c, G_PREPARE);
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
     if (b.d2.base) {
@@ -1163,7 +1165,7 @@ int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
   double sumsq = 0.0;
   long size = 0;
   {
-    Timer t(c, G_SWEEP);
+    Timer t(c, G_MRESID);
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       const BlockDev& b = c->blocks[n].d;
       if (b.d2.base) {

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- headline measurement of the accelerated hot path.
 
-Metric (BASELINE.json): Mcell-updates/s per iteration, where one iteration is
-one mgSolution::Iterate call (src/mgSolution.cpp:246) = one RK stage of the
-explicit-RK4 residual sweep, on a synthetic single-species 256^3-cell block
-(MUSCL thirdOrder + vanAlbada + Roe, slip walls, smooth perturbation) with the
-state resident in HBM.  `--workload lusgs` times BASELINE configs[2] instead
-(WENO5 + AUSMPW+ + viscous + LU-SGS).
+Metric (BASELINE.json): Mcell-updates/s per iteration (residual + LU-SGS) on a
+256^3 block, % of the HBM roofline.  One iteration = one mgSolution::Iterate
+call (src/mgSolution.cpp:246).  The default line is BASELINE configs[2]:
+single 256^3 block, WENO5 + AUSMPW+ + viscous fluxes, implicit Euler with one
+scalar LU-SGS sweep, state resident in HBM.  The same line carries, under
+"extra"."rk4", the explicit-RK4 residual sweep (MUSCL thirdOrder + vanAlbada +
+Roe, configs[1] at 256^3) that the north-star ">= 40 % of the HBM roofline"
+clause is stated on.  `--workload rk4|dplur8` make those the headline instead.
 
   python bench.py --gpus N --steps K --warmup W
 
@@ -132,6 +134,19 @@ def rank_local_chain_case(rank, nranks, n, workload, dims=None):
     return case
 
 
+# reference's own CPU figures measured during the survey,
+# quoted beside the port; they did not run on this box
+REFERENCE_SURVEY = {
+    "rk4": dict(value=0.058, unit="Mcell-updates/s", cores=1,
+                what="reference binary, MUSCL + vanAlbada + Roe, RK4, 32^3, 1 of 8 "
+                     "cores of the survey container (BASELINE.md section 2)"),
+    "lusgs": dict(value=0.0077, unit="Mcell-updates/s", cores=1,
+                  what="reference binary, shipped shockTube (WENO5 + Roe, bdf2, LU-SGS "
+                       "1 sweep, 2 x 50 cells), 1 core of the survey container "
+                       "(BASELINE.md section 2)"),
+}
+
+
 def cpu_baseline(workload, budget_s=12.0):
     """The CPU oracle (a from-scratch scalar port of the reference algorithm,
     NOT the reference binary) on a bounded sample of the same workload."""
@@ -143,58 +158,66 @@ def cpu_baseline(workload, budget_s=12.0):
     ora = abi.Api(ctypes.CDLL(lib), "ora_")
     n = 48
     case = rank_local_chain_case(0, 1, n, workload)
+    nonlin = case.deck.nonlinear_iterations
     s = Solver(ora, case)
     s.store_time_n(0)
     s.iterate(0, 0.5)                      # warm-up
     its, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
-        if its % 4 == 0:
-            s.store_time_n(its // 4)
-        s.iterate(its % 4, case.deck.cfl(0))
+        if its % nonlin == 0:
+            s.store_time_n(its // nonlin)
+        s.iterate(its % nonlin, case.deck.cfl(0))
         its += 1
     dt = time.perf_counter() - t0
     s.close()
-    return dict(value=n ** 3 * its / dt / 1e6, unit="Mcell-updates/s", cores=1,
-                kind="port",
-                sample=f"{its} iterations of the same scheme on a {n}^3 block "
-                       f"({dt:.1f} s, oracle/liboracle.so, gcc -O2, 1 thread)")
+    out = dict(value=n ** 3 * its / dt / 1e6, unit="Mcell-updates/s", cores=1,
+               kind="port",
+               sample=f"{its} iterations of the same scheme on a {n}^3 block "
+                      f"({dt:.1f} s, oracle/liboracle.so, gcc -O2, 1 thread)")
+    if workload in REFERENCE_SURVEY:
+        out["reference_survey"] = REFERENCE_SURVEY[workload]
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workload", choices=["rk4", "lusgs", "dplur8"], default="rk4")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="gloo stages the halo slabs through the host (rehearsal of "
-                         "the multi-rank path with several ranks on one GPU)")
-    ap.add_argument("--dims", default=None,
-                    help="ni,nj,nk of a non-cubic block (kernel experiments only)")
-    args = ap.parse_args()
+# algorithmic bytes per cell of the passes of one scalar LU-SGS iteration
+# (viscous: R 33 + F 43 + B 31 + M 35 + U 20 doubles = 1296 B) and
+# the timing groups (agx_timing_get) that implement each pass
+LUSGS_PASSES = [
+    ("R  residual + dt + diagonal (k_residual_tile, k_visc_march, k_lusgs_prepare)",
+     264, (0, 4, 5)),
+    ("F+B  LU-SGS forward + backward sweep (k_lusgs_kp x 2)", 344 + 248, (3,)),
+    ("M  matrix residual (k_matrix_resid_d2)", 280, (6,)),
+    ("U  update + norms (k_update_d2, k_norm_final)", 160, (1,)),
+]
+DPLUR_PASSES = [
+    ("R  residual + dt + diagonal", 240, (0, 4, 5)),
+    ("4 x DPLUR sweep (k_dplur)", 4 * 320, (3,)),
+    ("M  matrix residual", 280, (6,)),
+    ("U  update + norms", 160, (1,)),
+]
+WORKLOAD_TEXT = {
+    "rk4": ("residual + explicit RK4 stage update",
+            "single {n}^3 block per GPU, single-species air, MUSCL thirdOrder + "
+            "vanAlbada + Roe, RK4 explicit, slip walls",
+            "one mgSolution::Iterate call (one RK stage)"),
+    "lusgs": ("residual+LU-SGS",
+              "single {n}^3 block per GPU, single-species air, WENO5 + AUSMPW+ inviscid + "
+              "viscous fluxes, implicit Euler, scalar LU-SGS 1 sweep, viscous wall + "
+              "characteristic",
+              "one nonlinear iteration (mgSolution::Iterate)"),
+    "dplur8": ("residual + DPLUR",
+               "2x2x2 blocks of {h}^3 cells shared by the GPUs, Euler MUSCL + AUSMPW+, "
+               "implicit Euler DPLUR 4 sweeps, slip walls",
+               "one nonlinear iteration (mgSolution::Iterate)"),
+}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    if args.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1 and args.backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    elif world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    api = aither_amd.load()
+def run_workload(args, workload, api, world, rank, local_rank):
+    """Set the case up, warm up, time `args.steps` iterations; returns the
+    measured quantities of this rank (rank 0 holds the max-over-ranks time)."""
     n = args.size
     dims = tuple(int(v) for v in args.dims.split(",")) if args.dims else None
-    case = rank_local_chain_case(rank, world, n, args.workload, dims)
+    case = rank_local_chain_case(rank, world, n, workload, dims)
     nonlin = case.deck.nonlinear_iterations
     if world > 1:
         def exchange(items):
@@ -222,6 +245,7 @@ def main():
         def alloc(cnt):
             return torch.empty(max(int(cnt), 1), dtype=torch.float64, device="cuda")
         sol = PhasedSolver(api, case, rank, exchange, alloc, device=local_rank)
+        red_dev = "cuda" if args.backend == "nccl" else "cpu"
     else:
         sol = Solver(api, case, device=local_rank)
 
@@ -229,7 +253,16 @@ def main():
         mm = it % nonlin
         if mm == 0:
             sol.store_time_n(it // nonlin)
-        return sol.iterate(mm, case.deck.cfl(it // nonlin))
+        l2, linf, mres = sol.iterate(mm, case.deck.cfl(it // nonlin))
+        if world > 1:
+            # the reference reduces the norms over the ranks every iteration
+            # (main.cpp:254-264): part of the timed region
+            t = torch.tensor(list(l2) + [mres], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            m = torch.tensor([linf.linf], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+            l2 = t[:-1].cpu().numpy()
+        return l2, linf, mres
 
     it = 0
     for _ in range(args.warmup):
@@ -257,98 +290,163 @@ def main():
     if not np.all(np.isfinite(l2)) and not os.environ.get("AGX_ABLATE"):
         raise SystemExit("non-finite residual")
 
-    def group(g):
+    groups = []
+    for g in range(7):
         ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
         api.check(api.timing_get(sol.ctx, g, ctypes.byref(ms), ctypes.byref(cnt)))
-        return ms.value, cnt.value
+        groups.append((ms.value, cnt.value))
+    sol.close()
+    cells_rank = dims[0] * dims[1] * dims[2] if dims else n ** 3
+    total_cells = cells_rank * world
+    if workload == "dplur8":      # strong scaling: the 8 blocks are divided
+        total_cells = 8 * (n // 2) ** 3
+        cells_rank = total_cells // world
+    return dict(workload=workload, n=n, elapsed=elapsed, groups=groups,
+                cells_rank=cells_rank, total_cells=total_cells)
 
+
+def traffic_entry(workload, cells_rank):
+    """HBM bytes from the PMC counters (separate rocprofv3 --pmc passes,
+    FETCH_SIZE x 2 per the gfx950 correction, WRITE_SIZE as read), collected by
+    tools/profile_round.sh into profiles/hbm_traffic.json."""
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(tp):
+        return None
+    with open(tp) as fh:
+        tr = json.load(fh).get(workload)
+    if tr and tr.get("cells") == cells_rank:
+        return tr
+    return None
+
+
+def build_line(args, res, world):
+    workload, n, steps = res["workload"], res["n"], args.steps
+    cells_rank, groups = res["cells_rank"], res["groups"]
+    value = res["total_cells"] * steps / res["elapsed"] / 1e6
+    tr = traffic_entry(workload, cells_rank)
+    if workload == "rk4":
+        t_res, n_res = groups[0]
+        t_upd, n_upd = groups[1]
+        fused = (os.environ.get("AGX_KERNEL", "tile") != "gather"
+                 and os.environ.get("AGX_NO_FUSE", "0") in ("", "0"))
+        # dominant kernel: one launch per RK stage per block.  Fused form
+        # (default): k_residual_tile does the whole stage (residual, dt,
+        # update, norms) = 296 B/cell; unfused: residual kernel 216 B/cell
+        # followed by k_update.
+        bpc = BYTES_STAGE if fused else BYTES_RESID_KERNEL
+        achieved = bpc * cells_rank / (t_res * 1e-3) / 1e9
+        stage_ms = t_res * n_res / max(steps, 1) + t_upd
+        roof = dict(bound="hbm",
+                    kernel=("k_residual_tile<MUSCL,vanAlbada,Roe,fused>" if fused
+                            else "residual kernel (unfused)"),
+                    achieved=achieved, peak=HBM_PEAK / 1e9, unit="GB/s",
+                    frac=achieved * 1e9 / HBM_PEAK,
+                    traffic=tr["bytes_per_launch"] if tr else None,
+                    bytes_per_cell=bpc, avg_launch_ms=t_res,
+                    stage=dict(bytes_per_cell=BYTES_STAGE, device_ms=stage_ms,
+                               frac=BYTES_STAGE * cells_rank /
+                               (stage_ms * 1e-3) / HBM_PEAK))
+    else:
+        passes = LUSGS_PASSES if workload == "lusgs" else DPLUR_PASSES
+        kern, dev_ms = [], 0.0
+        for name, bpc, gs in passes:
+            ms = sum(groups[g][0] * groups[g][1] for g in gs) / max(steps, 1)
+            dev_ms += ms
+            ent = dict(pass_=name, bytes_per_cell=bpc, device_ms=ms,
+                       frac=(bpc * cells_rank / (ms * 1e-3) / HBM_PEAK) if ms > 0 else None)
+            if tr and "passes" in tr:
+                ent["traffic"] = tr["passes"].get(name.split()[0])
+            kern.append(ent)
+        dev_ms += groups[2][0] * groups[2][1] / max(steps, 1)      # ghost cells / halo
+        total_bpc = sum(p[1] for p in passes)
+        # the dominant kernel of this iteration: the sweeps
+        _, sw_bpc, sw_g = passes[1]
+        sw_ms = sum(groups[g][0] * groups[g][1] for g in sw_g) / max(steps, 1)
+        achieved = sw_bpc * cells_rank / (sw_ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel=passes[1][0],
+                    achieved=achieved, peak=HBM_PEAK / 1e9, unit="GB/s",
+                    frac=achieved * 1e9 / HBM_PEAK,
+                    traffic=(tr["passes"].get(passes[1][0].split()[0])
+                             if tr and "passes" in tr else None),
+                    bytes_per_cell=sw_bpc, avg_launch_ms=sw_ms,
+                    iteration=dict(bytes_per_cell=total_bpc, device_ms=dev_ms,
+                                   achieved=total_bpc * cells_rank / (dev_ms * 1e-3) / 1e9,
+                                   frac=total_bpc * cells_rank / (dev_ms * 1e-3) / HBM_PEAK,
+                                   traffic=tr["bytes_per_iteration"] if tr else None),
+                    passes=kern)
+    metric, wl, itn = WORKLOAD_TEXT[workload]
+    return {
+        "metric": f"Mcell-updates/sec per iteration ({metric}), {n}^3 block; % HBM roofline",
+        "value": value, "unit": "Mcell-updates/s", "n_gpus": world,
+        "steps": steps, "warmup": args.warmup,
+        "ms_per_step": res["elapsed"] / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if workload == "dplur8" else "weak",
+        "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": wl.format(n=n, h=n // 2), "iteration": itn,
+                   "blocks": 8 if workload == "dplur8" else world,
+                   "cells_per_gpu": cells_rank,
+                   "halo": ("none" if world == 1 else
+                            "RCCL p2p between phases" if args.backend == "nccl" else
+                            "gloo through the host (rehearsal)")},
+        "roofline": roof,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--workload", choices=["rk4", "lusgs", "dplur8"], default="lusgs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extra.rk4 measurement of the default line")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo stages the halo slabs through the host (rehearsal of "
+                         "the multi-rank path with several ranks on one GPU)")
+    ap.add_argument("--dims", default=None,
+                    help="ni,nj,nk of a non-cubic block (kernel experiments only)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    if world > 1 and args.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    elif world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    api = aither_amd.load()
+    res = run_workload(args, args.workload, api, world, rank, local_rank)
+    extra = None
+    if args.workload == "lusgs" and world == 1 and not args.no_extra and not args.dims:
+        # the explicit-RK4 residual sweep the ">= 40 % of roofline" target is stated on
+        rk_args = argparse.Namespace(**vars(args))
+        rk_args.steps, rk_args.warmup = max(args.steps, 40), max(args.warmup, 8)
+        extra = (rk_args, run_workload(rk_args, "rk4", api, world, rank, local_rank))
     if rank == 0:
-        cells_rank = dims[0] * dims[1] * dims[2] if dims else n ** 3
-        total_cells = cells_rank * world
-        if args.workload == "dplur8":      # strong scaling: the 8 blocks are divided
-            total_cells = 8 * (n // 2) ** 3
-            cells_rank = total_cells // world
-        value = total_cells * args.steps / elapsed / 1e6
-        t_res, n_res = group(0)
-        t_upd, n_upd = group(1)
-        t_bc, n_bc = group(2)
-        t_swp, n_swp = group(3)
-        launches_per_step = n_res / max(args.steps, 1)
-        if args.workload == "rk4":
-            fused = (os.environ.get("AGX_KERNEL", "tile") != "gather"
-                     and os.environ.get("AGX_NO_FUSE", "0") in ("", "0"))
-            # dominant kernel: one launch per RK stage per block.  Fused form
-            # (default): k_residual_tile does the whole stage (residual, dt,
-            # update, norms) = 296 B/cell; unfused: residual kernel 216 B/cell
-            # followed by k_update.
-            bpc = BYTES_STAGE if fused else BYTES_RESID_KERNEL
-            achieved = bpc * cells_rank / (t_res * 1e-3) / 1e9
-            stage_ms = t_res * launches_per_step + t_upd
-            roof = dict(bound="hbm",
-                        kernel=("k_residual_tile<MUSCL,vanAlbada,Roe,fused>" if fused
-                                else "residual kernel (unfused)"),
-                        achieved=achieved, peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=achieved * 1e9 / HBM_PEAK, traffic=None,
-                        bytes_per_cell=bpc, avg_launch_ms=t_res,
-                        stage=dict(bytes_per_cell=BYTES_STAGE, device_ms=stage_ms,
-                                   frac=BYTES_STAGE * cells_rank /
-                                   (stage_ms * 1e-3) / HBM_PEAK))
-        else:
-            dev_ms = (t_res * n_res + t_upd * n_upd + t_bc * n_bc +
-                      t_swp * n_swp) / max(args.steps, 1)
-            bpc = BYTES_LUSGS_ITER if args.workload == "lusgs" else BYTES_DPLUR4_ITER
-            achieved = bpc * cells_rank / (dev_ms * 1e-3) / 1e9
-            roof = dict(bound="hbm",
-                        kernel=("LU-SGS" if args.workload == "lusgs" else "DPLUR") +
-                        " iteration (all kernels)",
-                        achieved=achieved, peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=achieved * 1e9 / HBM_PEAK, traffic=None,
-                        bytes_per_cell=bpc, avg_launch_ms=dev_ms,
-                        sweep_ms=t_swp * n_swp / max(args.steps, 1))
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp):
-            with open(tp) as fh:
-                tr = json.load(fh).get(args.workload)
-            if tr and tr.get("cells") == cells_rank:
-                # HBM bytes per launch of the dominant kernel from separate
-                # rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
-                # correction, calibrated for 8-B lanes; WRITE_SIZE as read)
-                roof["traffic"] = tr["bytes_per_launch"]
-                roof["traffic_detail"] = tr
-        out = {
-            "metric": "Mcell-updates/sec per iteration (" +
-                      {"rk4": "residual + explicit RK4 stage update",
-                       "lusgs": "residual + LU-SGS",
-                       "dplur8": "residual + DPLUR"}[args.workload] + f"), {n}^3 block",
-            "value": value, "unit": "Mcell-updates/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong" if args.workload == "dplur8" else "weak",
-            "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (
-                f"single {n}^3 block per GPU, single-species air, MUSCL "
-                "thirdOrder + vanAlbada + Roe, RK4 explicit, slip walls"
-                if args.workload == "rk4" else
-                f"single {n}^3 block per GPU, WENO5 + AUSMPW+ + viscous, "
-                "implicit Euler LU-SGS 1 sweep, viscous wall + characteristic"
-                if args.workload == "lusgs" else
-                f"2x2x2 blocks of {n // 2}^3 cells shared by the GPUs, Euler MUSCL + "
-                "AUSMPW+, implicit Euler DPLUR 4 sweeps, slip walls"),
-                "iteration": "one mgSolution::Iterate call (one RK stage)"
-                if args.workload == "rk4" else "one nonlinear iteration",
-                "blocks": 8 if args.workload == "dplur8" else world,
-                "cells_per_gpu": cells_rank,
-                "halo": ("none" if world == 1 else
-                         "RCCL p2p between phases" if args.backend == "nccl" else
-                         "gloo through the host (rehearsal)")},
-            "roofline": roof,
-        }
+        out = build_line(args, res, world)
+        if extra is not None:
+            e = build_line(extra[0], extra[1], world)
+            out["extra"] = {"rk4": {k: e[k] for k in (
+                "metric", "value", "unit", "steps", "warmup", "ms_per_step", "config",
+                "roofline")}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
+            if extra is not None:
+                out["extra"]["rk4"]["cpu_baseline"] = cpu_baseline("rk4", budget_s=8.0)
         print(json.dumps(out))
-    sol.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -242,8 +242,10 @@ int agx_halo_unpack(agx_ctx *ctx, int conn_id, int what, const double *dev_buf);
 
 /* ---- measurement helpers ----------------------------------------------- */
 /* average duration [ms] of the named kernel group since the last reset,
- * measured with hipEvents on the library's stream; group: 0 = residual,
- * 1 = update, 2 = bc, 3 = sweep */
+ * measured with hipEvents on the library's stream; group: 0 = inviscid residual
+ * (+ fused explicit stage), 1 = update + norms, 2 = ghost cells / halo,
+ * 3 = LU-SGS / DPLUR sweeps, 4 = viscous residual, 5 = implicit begin
+ * (diagonal, right-hand side), 6 = matrix residual */
 int agx_timing_enable(agx_ctx *ctx, int on);
 int agx_timing_get(agx_ctx *ctx, int group, double *avg_ms, int64_t *launches);
 int agx_timing_reset(agx_ctx *ctx);

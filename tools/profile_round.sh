@@ -8,11 +8,11 @@ tag=$1; shift
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- \
-  python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 4 "$@" > $out/bench_under_rocprof.json 2> $out/trace.log
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- \
+  python3 $R/bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 4 "$@" > $out/bench_under_rocprof.json 2> $out/trace.log
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c -d $out/pmc_$c -o p --output-format csv -- \
-    python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $out/pmc_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $c -d $out/pmc_$c -o p --output-format csv -- \
+    python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 "$@" > $out/pmc_$c.log 2>&1
 done
 python3 $R/tools/pmc_summary.py $out > $out/pmc.json
 cp $out/trace/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
