@@ -277,14 +277,19 @@ def find_connections(bcs, nodes, deck, ranks=None, local_pos=None):
 
 # --------------------------------------------------------------------------
 def _put_geom(recv, send, conn, blk_first):
-    """procBlock::PutGeomSlice for same-direction, orientation-1,
-    lower<->upper connections (procBlock.cpp:3165-3600).  Returns adjEdge."""
+    """procBlock::PutGeomSlice (procBlock.cpp:3165-3920) for any of the eight
+    orientations and any pair of patch directions.  Returns adjEdge.
+
+    The reference's rules, direction by direction of the receiving patch
+    (d3 normal, d1, d2 in-plane; the sender's d3/d1/d2 are matched in that order):
+      * d3 faces take the sender's d3 faces; for lower/lower or upper/upper pairs
+        the sender's index runs the other way (the face above the cell is taken
+        and the normal flipped, aFac3 = -1);
+      * d1 / d2 faces take the sender's d1 / d2 faces; where the orientation
+        reverses that direction (aFac1 / aFac2 = -1) the cell's upper face is
+        taken and the normal flipped;
+      * at the end of a line the receiving cell's upper face is filled too."""
     ng = recv.ng
-    if conn.orientation != 1 or conn.lower_lower_or_upper_upper() or \
-            conn.dir(3, 0) != conn.dir(3, 1):
-        raise NotImplementedError(
-            "ghost-geometry exchange is implemented for orientation 1, "
-            "lower<->upper connections on the same index direction")
     dst, src, meta = insert_maps(conn, blk_first, ng, recv.n, send.n)
     c_adj = meta["c_adj"]
     l1, l2, l3 = (meta[k].ravel() for k in ("l1", "l2", "l3"))
@@ -319,23 +324,42 @@ def _put_geom(recv, send, conn, blk_first):
     S = {d: sel(isrc[d]) + g for d in "ijk"}
     recv.vol.a[A["k"], A["j"], A["i"]] = send.vol.a[S["k"], S["j"], S["i"]]
     recv.center.a[A["k"], A["j"], A["i"]] = send.center.a[S["k"], S["j"], S["i"]]
-    d3n, d1n, d2n = c_adj.dir(3, 0), c_adj.dir(1, 0), c_adj.dir(2, 0)
+    d3r, d1r, d2r = c_adj.dir(3, 0), c_adj.dir(1, 0), c_adj.dir(2, 0)
+    d3s, d1s, d2s = c_adj.dir(3, 1), c_adj.dir(1, 1), c_adj.dir(2, 1)
     len1 = c_adj.d1e[0] - c_adj.d1s[0]
     len2 = c_adj.d2e[0] - c_adj.d2s[0]
-    ends = {d3n: sel(l3) == ng - 1,
-            d1n: sel(l1) == (len1 - 1),
-            d2n: sel(l2) == (len2 - 1)}
-    for f in "ijk":
-        for arr_r, arr_s in ((recv.farea[f], send.farea[f]),
-                             (recv.fcen[f], send.fcen[f])):
-            arr_r.a[A["k"], A["j"], A["i"]] = arr_s.a[S["k"], S["j"], S["i"]]
-            e = ends[f]
-            if np.any(e):
-                off = {d: (1 if d == f else 0) for d in "ijk"}
-                arr_r.a[A["k"][e] + off["k"], A["j"][e] + off["j"],
-                        A["i"][e] + off["i"]] = \
-                    arr_s.a[S["k"][e] + off["k"], S["j"][e] + off["j"],
-                            S["i"][e] + off["i"]]
+    o = c_adj.orientation
+    lluu = c_adj.lower_lower_or_upper_upper()
+    afac = {3: -1.0 if lluu else 1.0,
+            1: -1.0 if o in (3, 4, 7, 8) else 1.0,
+            2: -1.0 if o in (5, 6, 7, 8) else 1.0}
+
+    def put(dr, ds, a_off, s_off, mask, fac):
+        """receiver d`dr`-face of cell A (+a_off along dr) <- fac * sender d`ds`-face
+        of cell S (+s_off along ds), for the cells selected by mask"""
+        ai = {d: A[d][mask] + (a_off if d == dr else 0) for d in "ijk"}
+        si = {d: S[d][mask] + (s_off if d == ds else 0) for d in "ijk"}
+        area = send.farea[ds].a[si["k"], si["j"], si["i"]].copy()
+        if fac < 0.0:          # unitVec3dMag * negative: flip the unit normal only
+            area[..., :3] *= -1.0
+        recv.farea[dr].a[ai["k"], ai["j"], ai["i"]] = area
+        recv.fcen[dr].a[ai["k"], ai["j"], ai["i"]] = send.fcen[ds].a[si["k"], si["j"], si["i"]]
+
+    every = np.ones(A["i"].shape, dtype=bool)
+    # direction 3 (procBlock.cpp:3276-3300): with lower/lower or upper/upper the
+    # sender's d3 index is incremented for its d3 faces and runs backwards
+    s3 = 1 if lluu else 0
+    fac3 = -1 if lluu else 1
+    put(d3r, d3s, 0, s3, every, afac[3])
+    put(d3r, d3s, 1, s3 + fac3, sel(l3) == ng - 1, afac[3])
+    for dr, ds, af, lcur, lend in ((d1r, d1s, afac[1], sel(l1), len1 - 1),
+                                   (d2r, d2s, afac[2], sel(l2), len2 - 1)):
+        if af > 0.0:
+            put(dr, ds, 0, 0, every, af)
+            put(dr, ds, 1, 1, lcur == lend, af)
+        else:                  # reversed: upper / lower faces swap
+            put(dr, ds, 0, 1, every, af)
+            put(dr, ds, 1, 0, lcur == lend, af)
     return adj_edge
 
 

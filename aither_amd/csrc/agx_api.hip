@@ -98,6 +98,7 @@ struct agx_ctx {
   int num_cu = 256;          // persistent workgroups of the tile kernel
   bool eager_ghosts = true;  // AGX_EAGER_GHOSTS=0: fill ghost cells at the start of agx_iterate
   bool visc_gather = false;  // AGX_VISC=gather: one-thread-per-cell viscous kernel
+  bool visc_march = false;   // AGX_VISC=march: face-once form without LDS staging
   int lusgs_mode = 1;        // AGX_LUSGS=plane (0: launch per hyperplane on the SoA
                              // planes, comparison form) | kp (1, default: agx_lusgs.hpp)
   int spin_limit = 4000000;  // AGX_SPIN_LIMIT: polls before a waiting plane gives up
@@ -365,15 +366,19 @@ MarchPlan march_plan(const agx_ctx* c, const BlockDev& b) {
   return p;
 }
 
-template <int RECON, int LIM, int FLUX>
-void launch_inv_kernel(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
-                       const MarchArgs& ma, const MarchPlan& mp) {
+SlabDev make_slab(const BlockDev& b) {
   SlabDev sd;
   sd.base = b.vol - (long)PL_VOL * b.nplane;
   sd.nplane = b.nplane; sd.sx = b.sx; sd.sxy = b.sxy;
   sd.ni = b.ni; sd.nj = b.nj; sd.nk = b.nk; sd.ng = b.ng; sd.ioff = b.ioff;
   sd.st = (int)((b.state[0] - sd.base) / b.nplane);
   sd.sn = (int)((b.state2[0] - sd.base) / b.nplane);
+  return sd;
+}
+template <int RECON, int LIM, int FLUX>
+void launch_inv_kernel(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
+                       const MarchArgs& ma, const MarchPlan& mp) {
+  const SlabDev sd = make_slab(b);
   if (c->use_gather) {
     hipLaunchKernelGGL((k_inv_residual<RECON, LIM, FLUX>), cell_grid(b, CELL_BLOCK),
                        CELL_BLOCK, 0, c->stream, b, c->gas, c->sp, cfl);
@@ -703,7 +708,10 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
     if (ncu > 0) c->num_cu = ncu;
     if (const char* w = getenv("AGX_WORKGROUPS")) c->num_cu = std::max(1, atoi(w));
-    if (const char* w = getenv("AGX_VISC")) c->visc_gather = !strcmp(w, "gather");
+    if (const char* w = getenv("AGX_VISC")) {
+      c->visc_gather = !strcmp(w, "gather");
+      c->visc_march = !strcmp(w, "march");
+    }
     if (const char* w = getenv("AGX_EAGER_GHOSTS")) c->eager_ghosts = atoi(w) != 0;
     if (const char* w = getenv("AGX_LUSGS")) c->lusgs_mode = !strcmp(w, "plane") ? 0 : 1;
     if (const char* w = getenv("AGX_SPIN_LIMIT")) c->spin_limit = std::max(1, atoi(w));
@@ -1089,12 +1097,23 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
                            0, c->stream, blk.d, c->gas, c->sp, cfl);
       } else {
         const BlockDev& vb = blk.d;
-        const int gx = (vb.ni + VTI - 1) / VTI, gy = (vb.nj + VTJ - 1) / VTJ;
-        int nz = std::max(1, std::min(vb.nk / 8, (int)std::lround(2048.0 / (gx * gy))));
+        if (c->visc_march || (double)vb.nplane * 8.0 >= 4294967296.0) {
+          const int gx = (vb.ni + VTI - 1) / VTI, gy = (vb.nj + VTJ - 1) / VTJ;
+          int nz = std::max(1, std::min(vb.nk / 8, (int)std::lround(2048.0 / (gx * gy))));
+          const int kchunk = (vb.nk + nz - 1) / nz;
+          nz = (vb.nk + kchunk - 1) / kchunk;
+          hipLaunchKernelGGL(k_visc_march, dim3(gx, gy, nz), dim3(64, VTJ + 1), 0, c->stream,
+                             vb, c->gas, c->sp, cfl, kchunk);
+          continue;
+        }
+        // 62 x 6 owned cells per workgroup, k cut into chunks so that >= ~4
+        // workgroups per CU exist (the first pass of a chunk only primes the k-face)
+        const int gx = (vb.ni + VT_OI - 1) / VT_OI, gy = (vb.nj + VT_OJ - 1) / VT_OJ;
+        int nz = std::max(1, std::min(vb.nk / 16, (int)std::lround(4.0 * c->num_cu / (gx * gy))));
         const int kchunk = (vb.nk + nz - 1) / nz;
         nz = (vb.nk + kchunk - 1) / kchunk;
-        hipLaunchKernelGGL(k_visc_march, dim3(gx, gy, nz), dim3(64, VTJ + 1), 0, c->stream,
-                           vb, c->gas, c->sp, cfl, kchunk);
+        hipLaunchKernelGGL(k_visc_tile, dim3(gx, gy, nz), dim3(VT_L, VT_R), 0, c->stream,
+                           make_slab(vb), c->gas, c->sp, cfl, kchunk);
       }
     HIPCHK(hipGetLastError());
   }

@@ -1231,6 +1231,10 @@ k_visc_march(BlockDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
   }
 }
 
+}  // namespace agx
+#include "agx_visc_tile.hpp"
+namespace agx {
+
 // ---------------------------------------------------------------------------
 // boundary conditions
 // boundaryConditions::GetBCSurface boundaryConditions.cpp:109-170

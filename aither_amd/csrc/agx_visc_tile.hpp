@@ -1,0 +1,348 @@
+// agx_visc_tile.hpp -- viscous residual, staged through registers / shuffles / LDS.
+//
+// Counterpart of procBlock::CalcViscFluxI/J/K (procBlock.cpp:1233-2135, laminar,
+// central reconstruction) with CalcGradsI/J/K (:5173-5786), VectorGradGG /
+// ScalarGradGG (utility.cpp:59-188), viscousFlux::CalcFlux (viscousFlux.cpp:58-135),
+// TauNormal (utility.cpp:426-437) and the viscous part of the time step / scalar
+// diagonal (ViscCellSpectralRadius spectralRadius.hpp:94-124).
+//
+// A face needs a ten-cell stencil of (u, v, w, T) and eleven face-area vectors;
+// read from global memory per face (k_visc_march) that is ~300 vector-memory
+// instructions per thread and k-step and 4.2 x the compulsory HBM traffic.  Here
+// a workgroup of 64 x 8 threads sits on 64 x 8 cells of a k-plane and marches
+// along k; each thread
+//   * keeps the k-stencil of ITS column in registers (three planes of u,v,w,T,
+//     the area vectors of two / three planes), loading one new plane per step,
+//   * publishes its column once per step in LDS, where the i- and j-neighbours
+//     read it (only the finished i-flux is handed over by a wave shuffle),
+// and evaluates the lower i-, lower j- and upper k-face of its cell once.  Lane 0
+// / row 0 only supply data, lane 63 / row 7 only the face their neighbour lacks:
+// 62 x 6 cells are owned per workgroup.  Per thread and step: ~45 vector-memory
+// instructions, every plane of the block read once per workgroup.
+#pragma once
+
+namespace agx {
+
+constexpr int VT_L = 64, VT_R = 8;           // threads: lanes (i) x rows (j)
+constexpr int VT_OI = VT_L - 2, VT_OJ = VT_R - 2;   // owned cells per workgroup
+// LDS: what a thread publishes for its neighbours, [var][row][lane]
+enum { VS_S0 = 0, VS_SM = 4, VS_SP = 8, VS_AI0 = 12, VS_AJ0 = 15, VS_AJ1 = 18, VS_AK0 = 21,
+       VS_AK1 = 24, VS_VOL = 27, VS_WJ = 28, VS_RHO = 29, VS_MU = 30, VS_AI1 = 31, VS_WI = 34,
+       VS_FJ = 35, VS_COUNT = 39 };
+
+#ifndef VT_EDGE_BARRIER
+#define VT_EDGE_BARRIER __builtin_amdgcn_sched_barrier(0)
+#endif
+// operand of a face: a slot of the LDS window, (var, row, lane)
+struct VRef { int var, row, lane; };
+// [row][lane][var]: the eight (row, lane) bases a thread uses live in registers, the
+// variable is an immediate offset; 39 doubles per slot (odd) => conflict-free
+using VShared = double (*)[VT_L][VS_COUNT];
+__device__ __forceinline__ void vt_ld4(VShared sh, const VRef& r, double* o) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = sh[r.row][r.lane][r.var + c];
+}
+__device__ __forceinline__ void vt_ld3(VShared sh, const VRef& r, double* o) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = sh[r.row][r.lane][r.var + c];
+}
+// grad[r][c] += sg * val[c] * a[r]
+__device__ __forceinline__ void vt_acc(double (*grad)[4], const double* val, const double* a,
+                                       double sg) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double w = sg * a[r];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) grad[r][c] = fma(val[c], w, grad[r][c]);
+  }
+}
+// one closing face of the dual volume at a transverse edge: the mean of the four
+// cells around the edge (vL, vU and two more) times the mean of two area vectors
+struct VtEdge { VRef c0, c1, a0, a1; };
+__device__ __forceinline__ void vt_edge(VShared sh, double (*grad)[4], const double* vsum,
+                                        const VtEdge& e, double sg) {
+  double c0[4], c1[4], a0[3], a1[3], v[4], a[3];
+  vt_ld4(sh, e.c0, c0); vt_ld4(sh, e.c1, c1);
+  vt_ld3(sh, e.a0, a0); vt_ld3(sh, e.a1, a1);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = 0.25 * (vsum[c] + c0[c] + c1[c]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) a[r] = 0.5 * (a0[r] + a1[r]);
+  vt_acc(grad, v, a, sg);
+  VT_EDGE_BARRIER;   // keep the operands of the next edge out of flight
+}
+// One face.  L | U: the cells across it; aF the face's area vector, aFm / aFp the
+// area vectors of the same-direction faces below / above (registers or LDS);
+// per transverse direction the upper / lower edge.  Operands are fetched from the
+// LDS window just in time: held all at once they do not fit the register file.
+__device__ __forceinline__ void vt_face(VShared sh, const GasDev& g, const VRef& rL,
+                                        const VRef& rU, const VRef& rhoL, const VRef& rhoU,
+                                        double rhoU_reg, double muU_reg, bool u_in_reg,
+                                        const double* uReg, const double* aF, const double* aFm,
+                                        const double* aFp, const VtEdge& t1u, const VtEdge& t1l,
+                                        const VtEdge& t2u, const VtEdge& t2l, double volL,
+                                        double volU, double wL, double wU, double* f) {
+  double grad[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) grad[r][c] = 0.0;
+  double vL[4], vU[4], vsum[4];
+  vt_ld4(sh, rL, vL);
+  if (u_in_reg) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vU[c] = uReg[c];
+  } else {
+    vt_ld4(sh, rU, vU);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) vsum[c] = vL[c] + vU[c];
+  {
+    double au[3], al[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { au[r] = 0.5 * (aF[r] + aFp[r]); al[r] = 0.5 * (aF[r] + aFm[r]); }
+    vt_acc(grad, vU, au, 1.0);
+    vt_acc(grad, vL, al, -1.0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  vt_edge(sh, grad, vsum, t1u, 1.0);
+  vt_edge(sh, grad, vsum, t1l, -1.0);
+  vt_edge(sh, grad, vsum, t2u, 1.0);
+  vt_edge(sh, grad, vsum, t2l, -1.0);
+  const double inv_vol = fast_rcp(0.5 * (volL + volU));
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) grad[r][c] *= inv_vol;
+  // FaceReconCentral reconstruction.hpp:315-328: the reference forms
+  // coeffs[0] * varD + coeffs[1] * varU with coeffs = {wD, wU} / (wU + wD)
+  // (wU: the cell below the face, wD: the cell above)
+  const double iw = fast_rcp(wL + wU);
+  const double cD = wU * iw, cU = wL * iw;
+  const double vf[3] = {cD * vU[0] + cU * vL[0], cD * vU[1] + cU * vL[1], cD * vU[2] + cU * vL[2]};
+  // T of the face-averaged state: p_f / (rho_f R) with p = rho R T
+  const double rL_ = sh[rhoL.row][rhoL.lane][rhoL.var];
+  const double mL_ = sh[rhoL.row][rhoL.lane][rhoL.var + 1];          // VS_MU = VS_RHO + 1
+  const double rU_ = u_in_reg ? rhoU_reg : sh[rhoU.row][rhoU.lane][rhoU.var];
+  const double mU_ = u_in_reg ? muU_reg : sh[rhoU.row][rhoU.lane][rhoU.var + 1];
+  const double rf = cD * rU_ + cU * rL_;
+  const double tf = (cD * rU_ * vU[3] + cU * rL_ * vL[3]) * fast_rcp(rf);
+  const double mu = g.scaling * (cD * mU_ + cU * mL_);
+  const double lambda = -(2.0 / 3.0) * mu;
+  const double trace = grad[0][0] + grad[1][1] + grad[2][2];
+  // tau . A  (viscousFlux.cpp:58-135 with the area vector instead of n |A|)
+  double tau[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double mm = (grad[r][0] + grad[0][r]) * aF[0] + (grad[r][1] + grad[1][r]) * aF[1] +
+                      (grad[r][2] + grad[2][r]) * aF[2];
+    tau[r] = lambda * trace * aF[r] + mu * mm;
+  }
+  const double kk = conductivity(g, tf) * g.scaling;
+  const double tg = grad[0][3] * aF[0] + grad[1][3] * aF[1] + grad[2][3] * aF[2];
+  f[0] = tau[0];
+  f[1] = tau[1];
+  f[2] = tau[2];
+  f[3] = dot3(tau, vf) + kk * tg;
+}
+
+__global__ void __launch_bounds__(VT_L * VT_R)
+k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
+  __shared__ double sh[VT_R][VT_L][VS_COUNT];
+  const int l = threadIdx.x, ty = threadIdx.y;
+  const int ci = blockIdx.x * VT_OI - 1 + l, cj = blockIdx.y * VT_OJ - 1 + ty;
+  const int k0 = blockIdx.z * kchunk, k1 = min(k0 + kchunk, b.nk);
+  const bool inner = l >= 1 && l <= VT_OI && ty >= 1 && ty <= VT_OJ;
+  const bool own = inner && ci < b.ni && cj < b.nj;
+  // lower i-face: own cell or the owned cell to the left; lower j-face likewise
+  const bool do_i = l >= 1 && ty >= 1 && ty <= VT_OJ && ci <= b.ni && cj < b.nj;
+  const bool do_j = ty >= 1 && l >= 1 && l <= VT_OI && cj <= b.nj && ci < b.ni;
+  const int ic = min(ci, b.ni), jc = min(cj, b.nj);      // overhanging threads stay in bounds
+  // one 32-bit byte offset per lane (column base, k = 0) + wave-uniform plane
+  // offsets; every array is "slab plane base (SGPRs) + offset" (SlabDev::ldb).
+  // Unsigned wrap-around makes the k = -1 plane come out right.
+  const unsigned qc = (unsigned)(b.idx(ic, jc, 0) * 8);
+  const unsigned sk = (unsigned)(b.sxy * 8), sj = (unsigned)(b.sx * 8);
+  const int kcmax = b.nk + b.ng - 1, kfmax = b.nk + b.ng; // last valid cell / face plane
+  auto ld_state = [&](int k, double* s4, double& rho, double& mu) {
+    const unsigned q = qc + (unsigned)min(k, kcmax) * sk;
+    rho = b.ldb(b.st + 0, q);
+    s4[0] = b.ldb(b.st + 1, q); s4[1] = b.ldb(b.st + 2, q); s4[2] = b.ldb(b.st + 3, q);
+    s4[3] = rho > 0.0 ? b.ldb(b.st + 4, q) * fast_rcp(rho * g.R) : 0.0;
+    mu = rho > 0.0 ? viscosity(g, s4[3]) : 0.0;
+  };
+  auto ld_avec = [&](int d, unsigned q, double* a3) {
+    const double mag = b.ldb(PL_FA + 4 * d + 3, q);
+    a3[0] = b.ldb(PL_FA + 4 * d + 0, q) * mag; a3[1] = b.ldb(PL_FA + 4 * d + 1, q) * mag;
+    a3[2] = b.ldb(PL_FA + 4 * d + 2, q) * mag;
+  };
+  auto PUT4 = [&](int var, const double* v) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sh[ty][l][var + c] = v[c];
+  };
+  auto PUT3 = [&](int var, const double* v) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sh[ty][l][var + c] = v[c];
+  };
+  auto LD4 = [&](int var, int row, int lane, double* o) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = sh[row][lane][var + c];
+  };
+  auto LD3 = [&](int var, int row, int lane, double* o) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = sh[row][lane][var + c];
+  };
+  // ---- the window of the own column (planes kk-1, kk, kk+1) lives in the
+  // thread's own LDS slots; registers hold only what nobody else reads.  kk starts
+  // one plane early: the first pass only forms the k-face below the chunk ----
+  int kk = k0 - 1;
+  double R1, MU1, V1, WK0, WK1, AK2[3], AIp[3], AJp[3];
+  {
+    double t4[4], t3[3], r, m;
+    const unsigned qk = qc + (unsigned)kk * sk;
+    ld_state(kk, t4, r, m);
+    PUT4(VS_S0, t4); PUT4(VS_SM, t4);
+    sh[ty][l][VS_RHO] = r; sh[ty][l][VS_MU] = m;
+    ld_state(kk + 1, t4, R1, MU1);
+    PUT4(VS_SP, t4);
+    ld_avec(0, qk, t3); PUT3(VS_AI0, t3);
+    ld_avec(0, qk + sk, t3); PUT3(VS_AI1, t3);
+    ld_avec(1, qk, t3); PUT3(VS_AJ0, t3);
+    ld_avec(1, qk + sk, t3); PUT3(VS_AJ1, t3);
+    ld_avec(2, qk, t3); PUT3(VS_AK0, t3);
+    ld_avec(2, qk + sk, t3); PUT3(VS_AK1, t3);
+    ld_avec(2, qc + (unsigned)min(kk + 2, kfmax) * sk, AK2);
+    ld_avec(0, qk + 8, AIp);
+    ld_avec(1, qk + sj, AJp);
+    sh[ty][l][VS_VOL] = b.ldb(PL_VOL, qk); V1 = b.ldb(PL_VOL, qk + sk);
+    WK0 = b.ldb(PL_WID + 2, qk); WK1 = b.ldb(PL_WID + 2, qk + sk);
+    sh[ty][l][VS_WI] = b.ldb(PL_WID + 0, qk); sh[ty][l][VS_WJ] = b.ldb(PL_WID + 1, qk);
+  }
+  double fk_lo[4] = {0, 0, 0, 0};
+  const int tu = min(ty + 1, VT_R - 1), td = max(ty - 1, 0);
+  const int lr = min(l + 1, VT_L - 1), ll = max(l - 1, 0);
+  for (; kk < k1; ++kk) {
+    const bool pre = kk < k0;                  // only the k-face of this pass is used
+    __syncthreads();                           // the windows of all columns are in place
+    // neighbours are read where they are used (i: lanes l -+ 1 of the own row, j:
+    // rows ty -+ 1); clamped indices only ever serve threads whose face is not needed
+    double fi[4] = {0, 0, 0, 0}, fj[4] = {0, 0, 0, 0}, fk_up[4] = {0, 0, 0, 0};
+    const VRef me0{VS_S0, ty, l}, meP{VS_SP, ty, l}, meM{VS_SM, ty, l};
+    const VRef meR{VS_RHO, ty, l};
+    // ---- lower i-face: cells (i-1,j) | (i,j) ----
+    if (do_i && !pre) {
+      double aF[3], aFm[3];
+      vt_ld3(sh, VRef{VS_AI0, ty, l}, aF); vt_ld3(sh, VRef{VS_AI0, ty, ll}, aFm);
+      const VtEdge ju{{VS_S0, tu, l}, {VS_S0, tu, ll}, {VS_AJ0, tu, l}, {VS_AJ0, tu, ll}};
+      const VtEdge jl{{VS_S0, td, l}, {VS_S0, td, ll}, {VS_AJ0, ty, l}, {VS_AJ0, ty, ll}};
+      const VtEdge ku{meP, {VS_SP, ty, ll}, {VS_AK1, ty, l}, {VS_AK1, ty, ll}};
+      const VtEdge kl{meM, {VS_SM, ty, ll}, {VS_AK0, ty, l}, {VS_AK0, ty, ll}};
+      vt_face(sh, g, VRef{VS_S0, ty, ll}, me0, VRef{VS_RHO, ty, ll}, meR, 0.0, 0.0, false,
+              nullptr, aF, aFm, AIp, ju, jl, ku, kl, sh[ty][ll][VS_VOL], sh[ty][l][VS_VOL],
+              sh[ty][ll][VS_WI], sh[ty][l][VS_WI], fi);
+    }
+    // hand the i-flux to the lane on the left, the j-flux to the row below as soon
+    // as they exist: racc = +lower -upper (i) +lower (j)
+    double racc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) racc[c] = fi[c] - __shfl_down(fi[c], 1, 64);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- lower j-face: cells (i,j-1) | (i,j) ----
+    if (do_j && !pre) {
+      double aF[3], aFm[3];
+      vt_ld3(sh, VRef{VS_AJ0, ty, l}, aF); vt_ld3(sh, VRef{VS_AJ0, td, l}, aFm);
+      const VtEdge iu{{VS_S0, ty, lr}, {VS_S0, td, lr}, {VS_AI0, ty, lr}, {VS_AI0, td, lr}};
+      const VtEdge il{{VS_S0, ty, ll}, {VS_S0, td, ll}, {VS_AI0, ty, l}, {VS_AI0, td, l}};
+      const VtEdge ku{meP, {VS_SP, td, l}, {VS_AK1, ty, l}, {VS_AK1, td, l}};
+      const VtEdge kl{meM, {VS_SM, td, l}, {VS_AK0, ty, l}, {VS_AK0, td, l}};
+      vt_face(sh, g, VRef{VS_S0, td, l}, me0, VRef{VS_RHO, td, l}, meR, 0.0, 0.0, false, nullptr,
+              aF, aFm, AJp, iu, il, ku, kl, sh[td][l][VS_VOL], sh[ty][l][VS_VOL],
+              sh[td][l][VS_WJ], sh[ty][l][VS_WJ], fj);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { sh[ty][l][VS_FJ + c] = fj[c]; racc[c] += fj[c]; }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- request the plane that enters the window next step (in flight during
+    // the k-face) ----
+    double nS[4], nR, nMU, nAI[3], nAJ[3], nAK[3], nAIp[3], nAJp[3];
+    const unsigned qn = qc + (unsigned)(kk + 1) * sk;            // plane kk+1 (always valid)
+    const unsigned qn2 = qc + (unsigned)min(kk + 2, kcmax) * sk; // cells of plane kk+2
+    ld_state(kk + 2, nS, nR, nMU);
+    ld_avec(0, qn2, nAI);
+    ld_avec(1, qn2, nAJ);
+    ld_avec(2, qc + (unsigned)min(kk + 3, kfmax) * sk, nAK);
+    ld_avec(0, qn + 8, nAIp);
+    ld_avec(1, qn + sj, nAJp);
+    const double nV = b.ldb(PL_VOL, qn2), nWK = b.ldb(PL_WID + 2, qn2);
+    const double nwi = b.ldb(PL_WID + 0, qn), nwj = b.ldb(PL_WID + 1, qn);
+    // ---- upper k-face: cells (i,j,k) | (i,j,k+1) ----
+    const double R0 = sh[ty][l][VS_RHO], MU0 = sh[ty][l][VS_MU], V0 = sh[ty][l][VS_VOL];
+    if (own) {
+      double aF[3], aFm[3], SPr[4];
+      vt_ld3(sh, VRef{VS_AK1, ty, l}, aF); vt_ld3(sh, VRef{VS_AK0, ty, l}, aFm);
+      vt_ld4(sh, meP, SPr);
+      const VtEdge iu{{VS_SP, ty, lr}, {VS_S0, ty, lr}, {VS_AI1, ty, lr}, {VS_AI0, ty, lr}};
+      const VtEdge il{{VS_SP, ty, ll}, {VS_S0, ty, ll}, {VS_AI1, ty, l}, {VS_AI0, ty, l}};
+      const VtEdge ju{{VS_SP, tu, l}, {VS_S0, tu, l}, {VS_AJ1, tu, l}, {VS_AJ0, tu, l}};
+      const VtEdge jl{{VS_SP, td, l}, {VS_S0, td, l}, {VS_AJ1, ty, l}, {VS_AJ0, ty, l}};
+      vt_face(sh, g, me0, meP, meR, meR, R1, MU1, true, SPr, aF, aFm, AK2, iu, il, ju, jl, V0, V1,
+              WK0, WK1, fk_up);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                           // all faces done: the windows may rotate
+    if (own && !pre) {
+      const unsigned q = qc + (unsigned)kk * sk;
+      double res[AGX_NEQ];
+#pragma unroll
+      for (int e = 1; e < AGX_NEQ; ++e) res[e] = b.ldb(PL_RESID + e, q);
+      // +lower -upper per direction
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        res[1 + c] += ((racc[c] - sh[ty + 1][l][VS_FJ + c]) + fk_lo[c]) - fk_up[c];
+      // ViscCellSpectralRadius spectralRadius.hpp:94-124
+      const double ivol = fast_rcp(V0);
+      const double vfac = visc_max_term(g, R0) * visc_term(g, MU0);
+      double sr = b.ldb(PL_SPECRAD, q);
+      double diag = sp.implicit ? b.ldb(PL_A, q) : 0.0;
+      // |A| of the six faces from the area vectors (n |A| was formed at load time)
+      double ai0[3], aj0[3], ak0[3], ak1[3];
+      LD3(VS_AI0, ty, l, ai0); LD3(VS_AJ0, ty, l, aj0);
+      LD3(VS_AK0, ty, l, ak0); LD3(VS_AK1, ty, l, ak1);
+      const double fm[3] = {0.5 * (fast_sqrt(dot3(ai0, ai0)) + fast_sqrt(dot3(AIp, AIp))),
+                            0.5 * (fast_sqrt(dot3(aj0, aj0)) + fast_sqrt(dot3(AJp, AJp))),
+                            0.5 * (fast_sqrt(dot3(ak0, ak0)) + fast_sqrt(dot3(ak1, ak1)))};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double vsr = vfac * fm[d] * fm[d] * ivol;
+        sr += vsr * sp.visc_cfl_coeff;
+        diag += 2.0 * vsr;
+      }
+#pragma unroll
+      for (int e = 1; e < AGX_NEQ; ++e) b.stb(PL_RESID + e, q, res[e]);   // mass: no viscous flux
+      b.stb(PL_SPECRAD, q, sr);
+      if (sp.implicit) b.stb(PL_A, q, diag);
+      b.stb(PL_DT, q, sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (V0 * fast_rcp(fmax(sr, 0.0))));
+    }
+    // ---- rotate the window in the own LDS slots ----
+    {
+      double t3[3], t4[4];
+      LD4(VS_S0, ty, l, t4); PUT4(VS_SM, t4);
+      LD4(VS_SP, ty, l, t4); PUT4(VS_S0, t4);
+      PUT4(VS_SP, nS);
+      sh[ty][l][VS_RHO] = R1; R1 = nR;
+      sh[ty][l][VS_MU] = MU1; MU1 = nMU;
+      LD3(VS_AI1, ty, l, t3); PUT3(VS_AI0, t3); PUT3(VS_AI1, nAI);
+      LD3(VS_AJ1, ty, l, t3); PUT3(VS_AJ0, t3); PUT3(VS_AJ1, nAJ);
+      LD3(VS_AK1, ty, l, t3); PUT3(VS_AK0, t3); PUT3(VS_AK1, AK2);
+      sh[ty][l][VS_VOL] = V1; V1 = nV;
+      sh[ty][l][VS_WI] = nwi; sh[ty][l][VS_WJ] = nwj;
+      WK0 = WK1; WK1 = nWK;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) fk_lo[c] = fk_up[c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { AK2[c] = nAK[c]; AIp[c] = nAIp[c]; AJp[c] = nAJp[c]; }
+    }
+  }
+}
+
+}  // namespace agx

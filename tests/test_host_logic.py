@@ -134,6 +134,49 @@ def test_halo_maps_python_vs_oracle(oracle):
     sol.close()
 
 
+def test_uniformflow_all_eight_orientations(oracle):
+    """The reference's uniformFlow grid (regressionTests.py:478-495) joins ten
+    blocks with every one of the eight patch orientations, lower/lower and
+    upper/upper pairs and i<->j / j<->k patch pairs (run here as an Euler deck).
+    (1) the numpy restatement of GetSwapLoc (boundaryConditions.cpp:3006-3181)
+    and the oracle's C restatement move the same cells for every connection;
+    (2) with the ghost geometry swapped by the general PutGeomSlice rules a
+    uniform stream stays uniform: any mismatch of cells, faces or flipped normals
+    at a connection would show up as a residual there."""
+    case = golden_case("uniformFlow")
+    assert sorted({c.orientation for c in case.connections}) == list(range(1, 9))
+    assert any(c.lower_lower_or_upper_upper() for c in case.connections)
+    assert any(c.dir(3, 0) != c.dir(3, 1) for c in case.connections)
+    sol = Solver(oracle, case)
+    ng = case.ng
+    probes = []
+    for gb, blk in enumerate(case.blocks):
+        st = np.arange(blk.state.size, dtype=float).reshape(blk.state.shape) + 1e6 * gb
+        sol.upload("state", gb, st)
+        probes.append(st.reshape(-1, 5))
+    oracle.check(oracle.halo_swap_local(sol.ctx, abi.HALO_STATE))
+    expect = [p.copy() for p in probes]
+    for c in case.connections:     # each connection touches ghost cells of its own
+        b0, b1 = c.block
+        g0, g1 = case.blocks[b0].geom, case.blocks[b1].geom
+        d0, s1, _ = conn_mod.insert_maps(c, True, ng, g0.n, g1.n)
+        d1, s0, _ = conn_mod.insert_maps(c, False, ng, g1.n, g0.n)
+        expect[b0][d0] = probes[b1][s1]
+        expect[b1][d1] = probes[b0][s0]
+    for gb in range(len(case.blocks)):
+        assert np.array_equal(sol.download("state", gb).reshape(-1, 5), expect[gb]), gb
+    sol.close()
+    # free-stream preservation through all the connections
+    case = golden_case("uniformFlow")
+    sol = Solver(oracle, case)
+    out = sol.step(0)
+    from parity_utils import flux_scale
+    for gb in range(len(case.blocks)):
+        r = sol.download("residual", gb)
+        assert np.abs(r).max() < 1e-11 * flux_scale(case), (gb, np.abs(r).max())
+    sol.close()
+
+
 def test_interblock_matches_single_block(oracle):
     """Explicit scheme: two stacked blocks give the same residual as the one
     merged block (ghost cells at the connection equal the neighbour's cells)."""

@@ -73,6 +73,23 @@ def test_free_running_explicit_with_time_n(agx, oracle, ti):
     _close(sg, so)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("perturb", [0.0, 0.05])
+def test_uniformflow_all_orientations_parity(agx, oracle, perturb):
+    """Halo exchange over all eight patch orientations (the reference's
+    uniformFlow grid, run as an Euler LU-SGS deck with two sweeps): HIP path vs
+    oracle, and -- unperturbed -- the uniform stream stays uniform on the GPU."""
+    from parity_utils import flux_scale
+    case = golden_case("uniformFlow")
+    if perturb:
+        synthetic.perturbed_state(case, perturb)
+    sg, so = run_pair(agx, oracle, case, 3)
+    if not perturb:
+        for gb in sg.block_ids:
+            assert np.abs(sg.download("residual", gb)).max() < 1e-10 * flux_scale(case)
+    _close(sg, so)
+
+
 def _run_with_env(agx, case, steps, env):
     """State after `steps` time steps with the given AGX_* switches (they are
     read when the context is created)."""
@@ -286,10 +303,8 @@ def test_config2_128cubed_one_rk_step(agx, oracle):
 
 
 def test_config3_88cubed_lusgs_iterations(agx, oracle):
-    """configs[2] at 88^3: WENO5 + AUSMPW+ + viscous, LU-SGS.  11^3 = 1331 bricks,
-    more than the 1024 waves the single-launch sweep keeps resident, so the ticket
-    queue wraps and bricks wait on predecessors that other waves are still
-    working on."""
+    """configs[2] at 88^3: WENO5 + AUSMPW+ + viscous, LU-SGS: 88 pipelined
+    k-planes of 175 diagonals each, against the oracle."""
     wall = {3: ("viscousWall", 2), 1: ("characteristic", 1),
             2: ("characteristic", 1), 4: ("characteristic", 1)}
     case = synthetic.single_block_case(n=(88, 88, 88), stretch=1.2, bcs=wall,
@@ -335,7 +350,8 @@ def test_256cubed_implicit_freestream(agx):
     """configs[2]'s implicit machinery at full size without an oracle: a uniform
     state with far-field boundaries is a fixed point of the viscous LU-SGS
     iteration -- residual and update at round-off -- and the single-launch sweep
-    gets through its 32768 bricks (every wait satisfied, no spin-limit error).
+    gets through its 256 pipelined k-planes (every wait satisfied, no spin-limit
+    error).
     MUSCL + Roe here: the reference's WENO5 does not preserve a free stream to
     round-off (its residual is ~1e-8 of a face flux on any grid, oracle and HIP
     alike), so it cannot carry this property."""
@@ -353,3 +369,75 @@ def test_256cubed_implicit_freestream(agx):
     assert np.all(np.isfinite(st))
     assert np.abs(st - ref).max() < 1e-11 * np.abs(ref).max()
     s.close()
+
+
+@pytest.mark.gpu
+def test_config3_256cubed_real_scheme_fast_vs_simple_forms(agx):
+    """BASELINE configs[2] at FULL size with its own scheme (WENO5 + AUSMPW+ +
+    viscous fluxes, scalar LU-SGS): two iterations on the production kernels
+    (LDS-tiled inviscid and viscous residual, pipelined k-plane sweeps on the
+    diagonal-ordered arrays) against the same library's simple forms (one thread
+    per cell and six faces, one launch per hyperplane on the SoA planes), which
+    are the forms the oracle parity tests pin at small sizes.  Also: everything
+    stays finite and no k-plane runs into the spin limit (iterate returns 0)."""
+    wall = {3: ("viscousWall", 2), 1: ("characteristic", 1),
+            2: ("characteristic", 1), 4: ("characteristic", 1)}
+    case = synthetic.single_block_case(n=(256, 256, 256), stretch=1.2, bcs=wall,
+                                       amplitude=0.05, equation_set="navierStokes",
+                                       face_reconstruction="weno", limiter="none",
+                                       inviscid_flux="ausm",
+                                       time_integration="implicitEuler",
+                                       matrix_solver="lusgs", cfl=10.0)
+    fast = _run_with_env(agx, case, 2, {})
+    assert np.all(np.isfinite(fast))
+    simple = _run_with_env(agx, case, 2, {"AGX_LUSGS": "plane", "AGX_VISC": "gather",
+                                           "AGX_KERNEL": "gather"})
+    assert rel_err(fast, simple) < 1e-11
+
+
+@pytest.mark.gpu
+def test_config4_eight_128cubed_blocks(agx):
+    """BASELINE configs[3] at FULL size on one GPU: 2 x 2 x 2 blocks of 128^3.
+    (a) one explicit RK4 step on the eight blocks reproduces the single 256^3
+    block (the 12 halo slabs carry exactly what the stage kernel reads);
+    (b) its own scheme -- Euler MUSCL + AUSMPW+, DPLUR with 4 sweeps -- runs an
+    iteration that stays finite and changes the state by O(dt)."""
+    from aither_amd.case import builder as _bld
+    kw = dict(time_integration="rk4", cfl=0.5)
+    c8 = synthetic.cube_blocks_case(n=(128, 128, 128), splits=(2, 2, 2), **kw)
+    s8 = Solver(agx, c8)
+    s8.step(0)
+    g = c8.ng
+    parts = [s8.download("state", b)[g:-g, g:-g, g:-g] for b in range(8)]
+    s8.close()
+    deck = synthetic.make_deck(**kw)
+    deck.bcs = [synthetic.box_surfaces(256, 256, 256, None)]
+    c1 = _bld.build_case(None, deck=deck,
+                         coords=[synthetic.box_nodes(256, 256, 256, 1.0, lengths=(2.0, 2.0, 2.0))])
+    synthetic.perturbed_state(c1, 0.05)
+    s1 = Solver(agx, c1)
+    s1.step(0)
+    full = s1.download("state", 0)[g:-g, g:-g, g:-g]
+    s1.close()
+    del c1
+    for bk in range(2):
+        for bj in range(2):
+            for bi in range(2):
+                ref = full[bk * 128:(bk + 1) * 128, bj * 128:(bj + 1) * 128,
+                           bi * 128:(bi + 1) * 128]
+                assert rel_err(parts[bi + 2 * (bj + 2 * bk)], ref) < 1e-12
+    del full, parts
+    c8 = synthetic.cube_blocks_case(n=(128, 128, 128), splits=(2, 2, 2),
+                                    inviscid_flux="ausm", time_integration="implicitEuler",
+                                    matrix_solver="dplur", matrix_sweeps=4, cfl=10.0)
+    s8 = Solver(agx, c8)
+    out = s8.step(0)
+    assert np.all(np.isfinite(out["l2"])) and np.isfinite(out["matrix"])
+    for b in (0, 7):
+        st = s8.download("state", b)[g:-g, g:-g, g:-g]
+        ini = c8.blocks[b].state[g:-g, g:-g, g:-g]
+        assert np.all(np.isfinite(st))
+        d = np.abs(st - ini).max() / np.abs(ini).max()
+        assert 0.0 < d < 0.2
+    s8.close()
+
