@@ -11,7 +11,11 @@ LIMITER = {"none": 0, "vanAlbada": 1, "minmod": 2}
 FLUX = {"roe": 0, "ausm": 1}
 TIME = {"explicitEuler": 0, "rk4": 1, "implicitEuler": 2,
         "crankNicholson": 3, "bdf2": 4}
-SOLVER = {"lusgs": 0, "dplur": 1}
+SOLVER = {"lusgs": 0, "dplur": 1, "blusgs": 2, "bdplur": 3}
+EQN = {"euler": 0, "navierStokes": 1, "rans": 2}
+JACOBIAN = {"rusanov": 0, "approximateRoe": 1}
+VISC_RECON = {"central": 0, "centralFourth": 1}
+TURB = {"none": 0, "sst2003": 1, "kOmegaWilcox2006": 2, "sstdes": 3, "wale": 4}
 BC = {"slipWall": 0, "viscousWall": 1, "characteristic": 2, "inlet": 3,
       "supersonicInflow": 4, "supersonicOutflow": 5, "stagnationInlet": 6,
       "pressureOutlet": 7, "interblock": 8, "periodic": 9}
@@ -33,7 +37,8 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_eq", "n_ghost", "recon", "limiter", "inviscid_flux", "is_viscous",
         "time_integration", "matrix_solver", "matrix_sweeps",
-        "nonlinear_iterations")] + [(n, C.c_double) for n in (
+        "nonlinear_iterations", "equation_set", "inv_flux_jacobian",
+        "viscous_recon", "turbulence_model")] + [(n, C.c_double) for n in (
             "kappa", "theta", "zeta", "matrix_relaxation", "dual_time_cfl",
             "dt_nondim", "viscous_cfl_coeff")] + [("gas", Gas)]
 

@@ -218,6 +218,10 @@ def config_struct(case):
     cfg.matrix_solver = abi.SOLVER[d.matrix_solver]
     cfg.matrix_sweeps = d.matrix_sweeps
     cfg.nonlinear_iterations = d.nonlinear_iterations
+    cfg.equation_set = abi.EQN[d.equation_set]
+    cfg.inv_flux_jacobian = abi.JACOBIAN[d.inv_flux_jac]
+    cfg.viscous_recon = abi.VISC_RECON[d.viscous_face_reconstruction]
+    cfg.turbulence_model = abi.TURB.get(d.turbulence_model, 4)
     cfg.kappa = d.kappa
     cfg.theta, cfg.zeta = d.theta, d.zeta
     cfg.matrix_relaxation = d.matrix_relaxation

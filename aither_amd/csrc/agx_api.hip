@@ -765,6 +765,25 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
     return fail("n_eq = %d: this build covers the 5-equation single-species "
                 "set", cfg->n_eq);
   if (cfg->n_ghost < 1 || cfg->n_ghost > 3) return fail("n_ghost out of range");
+  // Never substitute: a scheme this build does not implement is an error here,
+  // not a different scheme silently (mgSolution.hpp:112-115 must mean the same).
+  if (cfg->equation_set != AGX_EQN_EULER && cfg->equation_set != AGX_EQN_NAVIER_STOKES)
+    return fail("equation_set %d: this build covers euler and navierStokes (RANS and its "
+                "turbulence closures are not built)", cfg->equation_set);
+  if ((cfg->equation_set == AGX_EQN_NAVIER_STOKES) != (cfg->is_viscous != 0))
+    return fail("equation_set %d contradicts is_viscous %d", cfg->equation_set, cfg->is_viscous);
+  if (cfg->turbulence_model != AGX_TURB_NONE)
+    return fail("turbulence_model %d is not built (laminar / inviscid only)",
+                cfg->turbulence_model);
+  if (cfg->inv_flux_jacobian != AGX_JACOBIAN_RUSANOV)
+    return fail("inv_flux_jacobian %d: only rusanov (RusanovScalarOffDiagonal, "
+                "fluxJacobian.cpp:122) is built; approximateRoe is not", cfg->inv_flux_jacobian);
+  if (cfg->viscous_recon != AGX_VISC_RECON_CENTRAL)
+    return fail("viscous_recon %d: only central (FaceReconCentral, reconstruction.hpp:315) "
+                "is built; centralFourth is not", cfg->viscous_recon);
+  if (cfg->matrix_solver != AGX_SOLVER_LUSGS && cfg->matrix_solver != AGX_SOLVER_DPLUR)
+    return fail("matrix_solver %d: the block-matrix solvers (blusgs, bdplur) are not built",
+                cfg->matrix_solver);
   c->cfg = *cfg;
   derive_gas(*cfg, c->gas);
   SolverDev& sp = c->sp;
@@ -1018,10 +1037,22 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
   if (field == AGX_FIELD_UPDATE && b.d.d2.base && d2_x_copy(c, b, 0)) return 1;
+  if (field == AGX_FIELD_TEMPERATURE || field == AGX_FIELD_VISCOSITY) {
+    // formed on demand from the current state into a scratch plane (the x_old
+    // plane of DPLUR: rebuilt at the start of every implicit iteration)
+    if (field == AGX_FIELD_VISCOSITY && !c->sp.viscous)
+      return fail("viscosity_ is only kept for viscous runs (procBlock.cpp:6171)");
+    double* scratch = b.d.xold[0];
+    hipLaunchKernelGGL(k_aux_field, dim3((b.d.nplane + 255) / 256), dim3(256), 0, c->stream,
+                       b.d, c->gas, field == AGX_FIELD_VISCOSITY ? 1 : 0, scratch);
+    HIPCHK(hipGetLastError());
+    double* one[1] = {scratch};
+    const int g = b.d.ng;
+    return download_aos(c, b, out, one, 1, b.d.ni + 2 * g, b.d.nj + 2 * g, b.d.nk + 2 * g, g);
+  }
   double* const* p; int nc, gh;
   if (field_info(b, field, &p, &nc, &gh))
-    return fail("field %d is not stored by this library (temperature and "
-                "viscosity are recomputed from the state on device)", field);
+    return fail("unknown field %d", field);
   const int g = gh ? b.d.ng : 0;
   return download_aos(c, b, out, p, nc, b.d.ni + 2 * g, b.d.nj + 2 * g, b.d.nk + 2 * g, g);
 }

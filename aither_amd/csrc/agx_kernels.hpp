@@ -1777,6 +1777,23 @@ k_matrix_resid(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
   norm_block_reduce(r, 0, active, partials + bid);
 }
 
+// procBlock::UpdateAuxillaryVariables (procBlock.cpp:6171): temperature_ and
+// viscosity_ are never stored on the device (every kernel recomputes them from the
+// state in registers); an output step that asks for them gets them formed into a
+// scratch plane.  which: 0 temperature, 1 laminar viscosity
+__global__ void __launch_bounds__(256) k_aux_field(BlockDev b, GasDev g, int which, double* out) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.nplane) return;
+  double s[AGX_NEQ];
+  load5(b.state, q, s);
+  double v = 0.0;
+  if (s[0] > 0.0) {
+    v = temperature(g, s);
+    if (which == 1) v = viscosity(g, v);
+  }
+  out[q] = v;
+}
+
 // ---------------------------------------------------------------------------
 // AoS (reference host layout) <-> SoA conversion at the boundary
 __global__ void k_aos_to_soa(const double* __restrict__ aos, Planes5 soa, int ncomp,

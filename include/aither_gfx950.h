@@ -39,7 +39,16 @@ enum { AGX_FLUX_ROE = 0, AGX_FLUX_AUSM = 1 }; /* inviscidFlux.hpp:484-507 */
 enum { AGX_TIME_EXPLICIT_EULER = 0, AGX_TIME_RK4 = 1,
        AGX_TIME_IMPLICIT_EULER = 2, AGX_TIME_CRANK_NICHOLSON = 3,
        AGX_TIME_BDF2 = 4 };                   /* input.cpp:259-275 */
-enum { AGX_SOLVER_LUSGS = 0, AGX_SOLVER_DPLUR = 1 }; /* input.cpp:843-858 */
+enum { AGX_SOLVER_LUSGS = 0, AGX_SOLVER_DPLUR = 1,
+       AGX_SOLVER_BLUSGS = 2, AGX_SOLVER_BDPLUR = 3 }; /* input.cpp:843-858 */
+enum { AGX_EQN_EULER = 0, AGX_EQN_NAVIER_STOKES = 1,
+       AGX_EQN_RANS = 2 };                    /* input::equationSet_, input.cpp:1033-1060 */
+enum { AGX_JACOBIAN_RUSANOV = 0,
+       AGX_JACOBIAN_APPROX_ROE = 1 };         /* input::InvFluxJac, fluxJacobian.cpp:196-238 */
+enum { AGX_VISC_RECON_CENTRAL = 0,
+       AGX_VISC_RECON_CENTRAL_4TH = 1 };      /* reconstruction.hpp:315-379 */
+enum { AGX_TURB_NONE = 0, AGX_TURB_SST2003 = 1, AGX_TURB_KW_WILCOX2006 = 2,
+       AGX_TURB_SST_DES = 3, AGX_TURB_WALE = 4 };  /* turbulence.hpp */
 
 /* boundary condition types, ghostStates.cpp:62-689 */
 enum { AGX_BC_SLIPWALL = 0, AGX_BC_VISCOUSWALL = 1, AGX_BC_CHARACTERISTIC = 2,
@@ -94,6 +103,12 @@ typedef struct agx_config {
   int32_t matrix_solver;     /* AGX_SOLVER_*                               */
   int32_t matrix_sweeps;     /* input::MatrixSweeps                        */
   int32_t nonlinear_iterations; /* input::NonlinearIterations              */
+  /* the rest of what the path depends on.  agx_config_set REFUSES every value
+   * this build does not implement (it never substitutes another scheme): */
+  int32_t equation_set;      /* AGX_EQN_*; must agree with is_viscous / n_eq */
+  int32_t inv_flux_jacobian; /* AGX_JACOBIAN_* (input::InvFluxJac)          */
+  int32_t viscous_recon;     /* AGX_VISC_RECON_* (input::ViscousFaceReconstruction) */
+  int32_t turbulence_model;  /* AGX_TURB_* (input::TurbulenceModel)         */
   double kappa;              /* MUSCL kappa (input.cpp:277-292)            */
   double theta, zeta;        /* Beam-Warming (input.cpp:261-270)           */
   double matrix_relaxation;  /* input::MatrixRelaxation                    */

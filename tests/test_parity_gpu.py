@@ -372,6 +372,35 @@ def test_256cubed_implicit_freestream(agx):
 
 
 @pytest.mark.gpu
+def test_temperature_viscosity_fields(agx, oracle):
+    """AGX_FIELD_TEMPERATURE / VISCOSITY (temperature_, viscosity_ of
+    UpdateAuxillaryVariables procBlock.cpp:6171): formed on demand from the state
+    the device holds; compared with the oracle's arrays for the same state."""
+    wall = {3: ("viscousWall", 2), 1: ("characteristic", 1),
+            2: ("characteristic", 1), 4: ("characteristic", 1)}
+    case = synthetic.single_block_case(n=(13, 11, 9), stretch=1.1, bcs=wall,
+                                       equation_set="navierStokes",
+                                       time_integration="implicitEuler",
+                                       matrix_solver="lusgs", cfl=5.0)
+    sg, so = Solver(agx, case), Solver(oracle, case)
+    sg.step(0), so.step(0)
+    # the oracle's aux arrays belong to the state its last residual saw: give the
+    # device exactly that state (ghost cells included)
+    so2 = Solver(oracle, case)
+    oracle.check(oracle.phase_bc_faces(so2.ctx)); oracle.check(oracle.phase_bc_edges(so2.ctx))
+    oracle.check(oracle.phase_residual(so2.ctx, 0, case.deck.cfl(0)))
+    sg.upload("state", 0, so2.download("state", 0))
+    g = case.ng
+    for f in ("temperature", "viscosity"):
+        a, b = sg.download(f, 0), so2.download(f, 0)
+        inner = (slice(g, -g),) * 3
+        assert rel_err(a[inner], b[inner]) < RTOL, f
+        # ghost layers except the block's corner lines, which nobody assigns
+        assert rel_err(a[g:-g, g:-g, :], b[g:-g, g:-g, :]) < RTOL, f
+    _close(sg, so, so2)
+
+
+@pytest.mark.gpu
 def test_config3_256cubed_real_scheme_fast_vs_simple_forms(agx):
     """BASELINE configs[2] at FULL size with its own scheme (WENO5 + AUSMPW+ +
     viscous fluxes, scalar LU-SGS): two iterations on the production kernels
