@@ -78,6 +78,20 @@ class Connection(C.Structure):
                 ("orientation", C.c_int32), ("is_interblock", C.c_int32)]
 
 
+class Slab(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("tag", C.c_int32), ("count", C.c_int64),
+                ("send", c_dp), ("recv", c_dp)]
+
+
+SWAP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(Slab), C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class Exchange(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("swap", SWAP_FN), ("allgather", ALLGATHER_FN),
+                ("nranks", C.c_int32), ("host_buffers", C.c_int32)]
+
+
 class Linf(C.Structure):
     _fields_ = [("linf", C.c_double), ("block", C.c_int32), ("i", C.c_int32),
                 ("j", C.c_int32), ("k", C.c_int32), ("eqn", C.c_int32),
@@ -116,6 +130,10 @@ SYMBOLS = {
     "halo_count": (C.c_int64, [_vp, _i, _i]),
     "halo_pack": (_i, [_vp, _i, _i, _vp]),
     "halo_unpack": (_i, [_vp, _i, _i, _vp]),
+    "set_exchange": (_i, [_vp, C.POINTER(Exchange)]),
+    "rccl_unique_id": (_i, [_vp]),
+    "rccl_exchange_create": (_i, [_vp, _vp, _i, _i]),
+    "halo_exchange": (_i, [_vp, _i]),
     "timing_enable": (_i, [_vp, _i]),
     "timing_get": (_i, [_vp, _i, c_dp, C.POINTER(C.c_int64)]),
     "timing_reset": (_i, [_vp]),

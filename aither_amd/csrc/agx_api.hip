@@ -6,6 +6,7 @@
 // mgSolution::Iterate (src/mgSolution.cpp:246-269).  There is no CPU compute
 // path here: every entry point fails loudly if HIP is unavailable.
 #include "agx_kernels.hpp"
+#include <rccl/rccl.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -85,6 +86,19 @@ struct agx_ctx {
   SolverDev sp;
   std::vector<Block> blocks;
   std::vector<Conn> conns;
+  // multi-rank: the installed exchange, one persistent slab pair per remote
+  // connection, and the norm records of all ranks
+  agx_exchange ex = {};
+  bool have_ex = false;
+  struct Remote { int cid; long count; double *send = nullptr, *recv = nullptr;
+                  double *hsend = nullptr, *hrecv = nullptr; };
+  std::vector<Remote> remote;
+  std::vector<agx_slab> slabs;
+  struct NormRecord { double l2[8]; double mres, linf; int32_t block, i, j, k, eqn, pad;
+                      double fill[3]; };     // 128 bytes
+  NormRecord* rec_dev = nullptr;        // [1 + nranks] device (RCCL)
+  NormRecord* rec_host = nullptr;       // [1 + nranks] pinned
+  ncclComm_t nccl = nullptr;
   NormPartial* partials = nullptr;
   long n_partials = 0;
   NormPartial* norm_out = nullptr;      // device, one per block
@@ -119,6 +133,8 @@ struct agx_ctx {
   double t_ms[G_NGROUP] = {};
   long t_n[G_NGROUP] = {};
 };
+
+static int my_side(const agx_ctx* c, const Conn& k);
 
 namespace {
 
@@ -606,7 +622,7 @@ int reduce_norms(agx_ctx* c, size_t blk_index, long nparts) {
 // gridLevel::GetBoundaryConditions gridLevel.cpp:287-319 for the blocks of this rank
 int fill_ghosts(agx_ctx* c) {
   if (agx_phase_bc_faces(c)) return 1;
-  if (agx_halo_swap_local(c, AGX_HALO_STATE)) return 1;
+  if (agx_halo_exchange(c, AGX_HALO_STATE)) return 1;
   return agx_phase_bc_edges(c);
 }
 int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
@@ -751,6 +767,15 @@ void agx_ctx_destroy(agx_ctx* c) {
   if (c->err_dev) hipFree(c->err_dev);
   if (c->err_host) hipHostFree(c->err_host);
   if (c->halo_buf) hipFree(c->halo_buf);
+  for (auto& r : c->remote) {
+    if (r.send) hipFree(r.send);
+    if (r.recv) hipFree(r.recv);
+    if (r.hsend) hipHostFree(r.hsend);
+    if (r.hrecv) hipHostFree(r.hrecv);
+  }
+  if (c->rec_dev) hipFree(c->rec_dev);
+  if (c->rec_host) hipHostFree(c->rec_host);
+  if (c->nccl) ncclCommDestroy(c->nccl);
   for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   delete c;
 }
@@ -989,6 +1014,42 @@ int agx_setup_finalize(agx_ctx* c) {
     }
   }
   if (ensure_halo_buf(c, 2 * max_halo)) return 1;
+  // persistent slab pairs of the connections to other ranks (sorted by connection
+  // id on every rank: the order RCCL's p2p matching relies on)
+  std::vector<std::pair<int, int>> per_peer;   // (peer, connections seen so far)
+  for (size_t n = 0; n < c->conns.size(); ++n) {
+    if (my_side(c, c->conns[n]) < 0) continue;
+    agx_ctx::Remote r;
+    r.cid = (int)n;
+    r.count = (long)agx_halo_count(c, (int)n, AGX_HALO_STATE);
+    HIPCHK(hipMalloc((void**)&r.send, sizeof(double) * std::max<long>(r.count, 1)));
+    HIPCHK(hipMalloc((void**)&r.recv, sizeof(double) * std::max<long>(r.count, 1)));
+    if (c->have_ex && c->ex.host_buffers) {
+      HIPCHK(hipHostMalloc((void**)&r.hsend, sizeof(double) * std::max<long>(r.count, 1)));
+      HIPCHK(hipHostMalloc((void**)&r.hrecv, sizeof(double) * std::max<long>(r.count, 1)));
+    }
+    c->remote.push_back(r);
+    const int s = my_side(c, c->conns[n]);
+    agx_slab sl;
+    sl.peer = c->conns[n].c.rank[1 - s];
+    // tag: ordinal among the connections with this peer (hosts create connections
+    // in the global order on every rank, so both sides count alike)
+    sl.tag = 0;
+    bool seen = false;
+    for (auto& pp : per_peer)
+      if (pp.first == sl.peer) { sl.tag = pp.second++; seen = true; }
+    if (!seen) per_peer.emplace_back(sl.peer, 1);
+    sl.count = r.count;
+    const bool hb = c->have_ex && c->ex.host_buffers;
+    sl.send = hb ? r.hsend : r.send;
+    sl.recv = hb ? r.hrecv : r.recv;
+    c->slabs.push_back(sl);
+  }
+  if (c->have_ex) {
+    const size_t nrec = 1 + (size_t)c->ex.nranks;
+    HIPCHK(hipMalloc((void**)&c->rec_dev, sizeof(agx_ctx::NormRecord) * nrec));
+    HIPCHK(hipHostMalloc((void**)&c->rec_host, sizeof(agx_ctx::NormRecord) * nrec));
+  }
   c->n_partials = max_parts;
   HIPCHK(hipMalloc((void**)&c->partials, sizeof(NormPartial) * max_parts));
   const size_t nb = std::max<size_t>(c->blocks.size(), 1);
@@ -1321,13 +1382,135 @@ int agx_halo_unpack(agx_ctx* c, int id, int what, const double* dev_buf) {
   return 0;
 }
 
+// ---- multi-rank -------------------------------------------------------------
+int agx_set_exchange(agx_ctx* c, const agx_exchange* ex) {
+  if (!ex || !ex->swap || !ex->allgather || ex->nranks < 1)
+    return fail("agx_set_exchange: swap, allgather and nranks are required");
+  if (c->finalized) return fail("agx_set_exchange must precede agx_setup_finalize");
+  c->ex = *ex;
+  c->have_ex = true;
+  return 0;
+}
+
+namespace {
+// built-in transport: RCCL on the library's stream
+int rccl_swap(void* user, int n, const agx_slab* slabs, void* stream) {
+  agx_ctx* c = static_cast<agx_ctx*>(user);
+  ncclResult_t r = ncclGroupStart();
+  for (int q = 0; q < n && r == ncclSuccess; ++q) {
+    r = ncclSend(slabs[q].send, (size_t)slabs[q].count, ncclDouble, slabs[q].peer, c->nccl,
+                 (hipStream_t)stream);
+    if (r == ncclSuccess)
+      r = ncclRecv(slabs[q].recv, (size_t)slabs[q].count, ncclDouble, slabs[q].peer, c->nccl,
+                   (hipStream_t)stream);
+  }
+  const ncclResult_t e = ncclGroupEnd();
+  if (r == ncclSuccess) r = e;
+  return r == ncclSuccess ? 0 : fail("RCCL halo exchange failed: %s", ncclGetErrorString(r));
+}
+int rccl_allgather(void* user, const void* send, void* recv, int64_t bytes, void* stream) {
+  agx_ctx* c = static_cast<agx_ctx*>(user);
+  const ncclResult_t r = ncclAllGather(send, recv, (size_t)bytes, ncclChar, c->nccl,
+                                       (hipStream_t)stream);
+  return r == ncclSuccess ? 0 : fail("RCCL all-gather failed: %s", ncclGetErrorString(r));
+}
+}  // namespace
+
+int agx_rccl_unique_id(void* id128) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  const ncclResult_t r = ncclGetUniqueId(static_cast<ncclUniqueId*>(id128));
+  return r == ncclSuccess ? 0 : fail("ncclGetUniqueId: %s", ncclGetErrorString(r));
+}
+int agx_rccl_exchange_create(agx_ctx* c, const void* id128, int nranks, int rank) {
+  if (c->finalized) return fail("agx_rccl_exchange_create must precede agx_setup_finalize");
+  HIPCHK(hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  const ncclResult_t r = ncclCommInitRank(&c->nccl, nranks, id, rank);
+  if (r != ncclSuccess) return fail("ncclCommInitRank: %s", ncclGetErrorString(r));
+  agx_exchange ex;
+  ex.user = c; ex.swap = rccl_swap; ex.allgather = rccl_allgather;
+  ex.nranks = nranks; ex.host_buffers = 0;
+  c->ex = ex;
+  c->have_ex = true;
+  return 0;
+}
+
+// gridLevel::GetBoundaryConditions (state) / lusgs::Relax, dplur::Relax (update):
+// local connections, then the slabs of connections to other ranks
+int agx_halo_exchange(agx_ctx* c, int what) {
+  if (agx_halo_swap_local(c, what)) return 1;
+  if (c->remote.empty()) return 0;
+  if (!c->have_ex) return fail("connections to other ranks need an exchange (agx_set_exchange)");
+  Timer t(c, G_BC);
+  for (auto& r : c->remote)
+    if (agx_halo_pack(c, r.cid, what, r.send)) return 1;
+  if (c->ex.host_buffers) {
+    for (auto& r : c->remote)
+      HIPCHK(hipMemcpyAsync(r.hsend, r.send, sizeof(double) * r.count, hipMemcpyDeviceToHost,
+                            c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  if (c->ex.swap(c->ex.user, (int)c->slabs.size(), c->slabs.data(), c->stream))
+    return g_err[0] ? 1 : fail("the exchange's swap operation failed");
+  if (c->ex.host_buffers)
+    for (auto& r : c->remote)
+      HIPCHK(hipMemcpyAsync(r.recv, r.hrecv, sizeof(double) * r.count, hipMemcpyHostToDevice,
+                            c->stream));
+  for (auto& r : c->remote)
+    if (agx_halo_unpack(c, r.cid, what, r.recv)) return 1;
+  return 0;
+}
+
+namespace {
+// main.cpp:254-264 over the exchange: every rank ends up with the global norms
+int reduce_over_ranks(agx_ctx* c, double* l2, agx_linf* linf, double* matrix_resid,
+                      const double* l2_in) {
+  typedef agx_ctx::NormRecord Rec;
+  const int nr = c->ex.nranks;
+  Rec& mine = c->rec_host[0];
+  memset(&mine, 0, sizeof mine);
+  for (int e = 0; e < AGX_NEQ; ++e) mine.l2[e] = l2[e] - l2_in[e];   // this call's local sums
+  mine.mres = *matrix_resid;
+  mine.linf = linf->linf; mine.block = linf->block; mine.i = linf->i; mine.j = linf->j;
+  mine.k = linf->k; mine.eqn = linf->eqn;
+  Rec* all = c->rec_host + 1;
+  if (c->ex.host_buffers) {
+    if (c->ex.allgather(c->ex.user, &mine, all, (int64_t)sizeof(Rec), c->stream))
+      return g_err[0] ? 1 : fail("the exchange's allgather operation failed");
+  } else {
+    HIPCHK(hipMemcpyAsync(c->rec_dev, &mine, sizeof(Rec), hipMemcpyHostToDevice, c->stream));
+    if (c->ex.allgather(c->ex.user, c->rec_dev, c->rec_dev + 1, (int64_t)sizeof(Rec), c->stream))
+      return 1;
+    HIPCHK(hipMemcpyAsync(all, c->rec_dev + 1, sizeof(Rec) * nr, hipMemcpyDeviceToHost,
+                          c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  // fold in rank order: the same result on every rank
+  double mres = 0.0;
+  for (int e = 0; e < AGX_NEQ; ++e) l2[e] = l2_in[e];
+  for (int r = 0; r < nr; ++r) {
+    for (int e = 0; e < AGX_NEQ; ++e) l2[e] += all[r].l2[e];
+    mres += all[r].mres;
+    if (all[r].linf > linf->linf) {
+      linf->linf = all[r].linf; linf->block = all[r].block; linf->i = all[r].i;
+      linf->j = all[r].j; linf->k = all[r].k; linf->eqn = all[r].eqn;
+    }
+  }
+  *matrix_resid = mres;
+  return 0;
+}
+}  // namespace
+
 // ---- mgSolution::Iterate (mgSolution.cpp:246-269) ---------------------------
 int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
                 double* matrix_resid) {
   if (!c->finalized) return fail("agx_setup_finalize has not been called");
-  for (auto& k : c->conns)
-    if (my_side(c, k) >= 0)
-      return fail("agx_iterate: remote connections need the phase API");
+  if (!c->remote.empty() && !c->have_ex)
+    return fail("agx_iterate: connections to other ranks need an exchange "
+                "(agx_set_exchange / agx_rccl_exchange_create) or the phase API");
+  double l2_in[AGX_NEQ];
+  for (int e = 0; e < AGX_NEQ; ++e) l2_in[e] = l2[e];
   // gridLevel::GetBoundaryConditions gridLevel.cpp:287-319 (already done behind the
   // previous call's norm read-back unless something touched the state since)
   if (!c->ghosts_prefilled && fill_ghosts(c)) return 1;
@@ -1337,23 +1520,28 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
   // gridLevel::CalcResidual :372-400 + CalcTimeStep :240-247
   if (agx_phase_residual(c, mm, cfl)) return 1;
   *matrix_resid = 0.0;
+  int rc;
   if (c->sp.implicit) {
     // mgSolution::ImplicitUpdate :209-244; lusgs::Relax linearSolver.cpp:430-470;
     // dplur::Relax :509-535
     if (agx_phase_implicit_begin(c)) return 1;
     for (int s = 0; s < c->cfg.matrix_sweeps; ++s) {
-      if (agx_halo_swap_local(c, AGX_HALO_UPDATE)) return 1;
+      if (agx_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
       if (agx_phase_relax_forward(c, s)) return 1;
       if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
-        if (agx_halo_swap_local(c, AGX_HALO_UPDATE)) return 1;
+        if (agx_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
         if (agx_phase_relax_backward(c, s)) return 1;
       }
     }
-    if (agx_halo_swap_local(c, AGX_HALO_UPDATE)) return 1;
+    if (agx_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
     if (agx_phase_matrix_residual(c, matrix_resid)) return 1;
-    return agx_phase_implicit_update(c, mm, l2, linf);
+    rc = agx_phase_implicit_update(c, mm, l2, linf);
+  } else {
+    rc = agx_phase_explicit_update(c, mm, l2, linf);
   }
-  return agx_phase_explicit_update(c, mm, l2, linf);
+  if (rc) return rc;
+  if (c->have_ex) return reduce_over_ranks(c, l2, linf, matrix_resid, l2_in);
+  return 0;
 }
 
 // ---- measurement ------------------------------------------------------------

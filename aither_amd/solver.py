@@ -19,14 +19,70 @@ from .case import builder as _b
 EPS = 1.0e-30  # macros.hpp.in:20
 
 
+class DistExchange:
+    """An agx_exchange (include/aither_gfx950.h) on torch.distributed
+    point-to-point with HOST buffers: what an MPI adapter would pass
+    (MPI_Sendrecv / MPI_Allgather), here over gloo for the multi-process tests.
+    The production transport is the library's own RCCL one
+    (agx_rccl_exchange_create)."""
+
+    def __init__(self, world):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.world = torch, dist, world
+        self._swap = abi.SWAP_FN(self.swap)
+        self._allgather = abi.ALLGATHER_FN(self.allgather)
+        self.struct = abi.Exchange(None, self._swap, self._allgather, world, 1)
+
+    def _view(self, ptr, n, dtype):
+        ct = C.c_double if dtype == np.float64 else C.c_uint8
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(max(int(n), 1),))
+        return self.torch.from_numpy(arr)[:int(n)]
+
+    def swap(self, user, n, slabs, stream):
+        reqs = []
+        for q in range(n):
+            sl = slabs[q]
+            if sl.count <= 0:
+                continue
+            reqs.append(self.dist.isend(self._view(sl.send, sl.count, np.float64),
+                                        sl.peer, tag=sl.tag))
+            reqs.append(self.dist.irecv(self._view(sl.recv, sl.count, np.float64),
+                                        sl.peer, tag=sl.tag))
+        for r in reqs:
+            r.wait()
+        return 0
+
+    def allgather(self, user, send, recv, nbytes, stream):
+        mine = self._view(send, nbytes, np.uint8).clone()
+        parts = [self.torch.empty(nbytes, dtype=self.torch.uint8) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        out = self._view(recv, nbytes * self.world, np.uint8)
+        for r, p in enumerate(parts):
+            out[r * nbytes:(r + 1) * nbytes] = p
+        return 0
+
+
 class Solver:
-    def __init__(self, api, case, device=0, rank=0, stream=None):
+    def __init__(self, api, case, device=0, rank=0, stream=None, exchange=None,
+                 rccl=None):
+        """exchange: a DistExchange-like object (multi-process, host buffers);
+        rccl: (id128 bytes, nranks, rank) for the library's RCCL transport.  With
+        either, iterate() handles connections to other ranks and returns the
+        globally reduced norms."""
         self.api, self.case, self.rank = api, case, rank
         self.ctx = C.c_void_p()
         api.check(api.ctx_create(device, rank, C.byref(self.ctx)), "ctx_create")
         if stream is not None:
             api.check(api.ctx_set_stream(self.ctx, C.c_void_p(stream)),
                       "ctx_set_stream")
+        self._exchange = exchange
+        if exchange is not None:
+            api.check(api.set_exchange(self.ctx, C.byref(exchange.struct)), "set_exchange")
+        if rccl is not None:
+            self._rccl_id = C.create_string_buffer(bytes(rccl[0]), 128)
+            api.check(api.rccl_exchange_create(self.ctx, self._rccl_id, rccl[1], rccl[2]),
+                      "rccl_exchange_create")
         self.cfg = _b.config_struct(case)
         api.check(api.config_set(self.ctx, C.byref(self.cfg)), "config_set")
         self._keep = []

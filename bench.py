@@ -13,9 +13,10 @@ clause is stated on.  `--workload rk4|dplur8` make those the headline instead.
   python bench.py --gpus N --steps K --warmup W
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling, one
-256^3 block per rank stacked along k and joined by interblock connections;
-ghost slabs are exchanged with RCCL point-to-point between the phases of the
-iteration (aither_amd.solver.PhasedSolver).
+256^3 block per rank stacked along k and joined by interblock connections; the
+library exchanges the ghost slabs itself with RCCL (grouped send/recv on its own
+stream, no host sync between pack and unpack) and all-gathers the norms
+(agx_rccl_exchange_create, include/aither_gfx950.h).
 """
 import argparse
 import ctypes
@@ -38,7 +39,7 @@ from aither_amd.case import synthetic
 from aither_amd.case import builder as _b
 from aither_amd.case import geometry as _geo
 from aither_amd.case import connections as _conn
-from aither_amd.solver import Solver, PhasedSolver
+from aither_amd.solver import Solver, DistExchange
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 BYTES_STAGE = 296          # explicit stage, nEq = 5
@@ -219,33 +220,19 @@ def run_workload(args, workload, api, world, rank, local_rank):
     dims = tuple(int(v) for v in args.dims.split(",")) if args.dims else None
     case = rank_local_chain_case(rank, world, n, workload, dims)
     nonlin = case.deck.nonlinear_iterations
-    if world > 1:
-        def exchange(items):
-            if args.backend == "gloo":
-                reqs, staged = [], []
-                for peer, tag, send, recv in items:
-                    hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-                    staged.append((recv, hr))
-                    reqs.append(dist.isend(hs, peer, tag=tag))
-                    reqs.append(dist.irecv(hr, peer, tag=tag))
-                for r in reqs:
-                    r.wait()
-                for recv, hr in staged:
-                    recv.copy_(hr)
-                torch.cuda.synchronize()
-                return
-            ops = []
-            for peer, tag, send, recv in items:
-                ops.append(dist.P2POp(dist.isend, send, peer, tag=tag))
-                ops.append(dist.P2POp(dist.irecv, recv, peer, tag=tag))
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            torch.cuda.current_stream().synchronize()
-
-        def alloc(cnt):
-            return torch.empty(max(int(cnt), 1), dtype=torch.float64, device="cuda")
-        sol = PhasedSolver(api, case, rank, exchange, alloc, device=local_rank)
-        red_dev = "cuda" if args.backend == "nccl" else "cpu"
+    if world > 1 and args.backend == "nccl":
+        # the library's own transport: RCCL on its stream (agx_rccl_exchange_create);
+        # torch.distributed only carries the 128-byte id to the other ranks
+        idbuf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            api.check(api.rccl_unique_id(idbuf), "rccl_unique_id")
+        t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).cuda()
+        dist.broadcast(t, src=0)
+        sol = Solver(api, case, device=local_rank, rank=rank,
+                     rccl=(bytes(t.cpu().numpy().tobytes()), world, rank))
+    elif world > 1:
+        # rehearsal: the same in-library path with host-staged slabs over gloo
+        sol = Solver(api, case, device=local_rank, rank=rank, exchange=DistExchange(world))
     else:
         sol = Solver(api, case, device=local_rank)
 
@@ -253,16 +240,9 @@ def run_workload(args, workload, api, world, rank, local_rank):
         mm = it % nonlin
         if mm == 0:
             sol.store_time_n(it // nonlin)
-        l2, linf, mres = sol.iterate(mm, case.deck.cfl(it // nonlin))
-        if world > 1:
-            # the reference reduces the norms over the ranks every iteration
-            # (main.cpp:254-264): part of the timed region
-            t = torch.tensor(list(l2) + [mres], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            m = torch.tensor([linf.linf], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(m, op=dist.ReduceOp.MAX)
-            l2 = t[:-1].cpu().numpy()
-        return l2, linf, mres
+        # with an exchange installed the norms come back reduced over the ranks
+        # (main.cpp:254-264): inside iterate, hence inside the timed region
+        return sol.iterate(mm, case.deck.cfl(it // nonlin))
 
     it = 0
     for _ in range(args.warmup):
@@ -388,8 +368,9 @@ def build_line(args, res, world):
                    "blocks": 8 if workload == "dplur8" else world,
                    "cells_per_gpu": cells_rank,
                    "halo": ("none" if world == 1 else
-                            "RCCL p2p between phases" if args.backend == "nccl" else
-                            "gloo through the host (rehearsal)")},
+                            "RCCL grouped send/recv + all-gather of the norms on the "
+                            "library's stream" if args.backend == "nccl" else
+                            "host-staged slabs over gloo (rehearsal)")},
         "roofline": roof,
     }
 

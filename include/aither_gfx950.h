@@ -221,8 +221,9 @@ int agx_store_time_n(agx_ctx *ctx, int also_nm1);
  *  l2   -- n_eq doubles, ACCUMULATED into (sum of residual^2, procBlock.cpp:858)
  *  linf -- updated only when a larger signed residual is found (:863-866)
  *  matrix_resid -- returns sum(matrixResid^2)/count (mgSolution.cpp:198-206)
- * Valid only when every connection has both sides on this rank; otherwise
- * drive the phases below and exchange halos between them. */
+ * With connections to other ranks: install an exchange first (agx_set_exchange /
+ * agx_rccl_exchange_create, below), or drive the phases and exchange the slabs
+ * yourself. */
 int agx_iterate(agx_ctx *ctx, int mm, double cfl, double *l2, agx_linf *linf,
                 double *matrix_resid);
 
@@ -254,6 +255,53 @@ int64_t agx_halo_count(agx_ctx *ctx, int conn_id, int what);
 int agx_halo_pack(agx_ctx *ctx, int conn_id, int what, double *dev_buf);
 /* unpack the partner's slab from dev_buf into this rank's ghost cells */
 int agx_halo_unpack(agx_ctx *ctx, int conn_id, int what, const double *dev_buf);
+
+/* ---- multi-rank runs: agx_iterate drives remote connections itself ---------
+ * In the reference a rank exchanges ghost slabs with SwapSliceParallel /
+ * PackSwapUnpackMPI (multiArray3d.hpp:830-866, utility.cpp:400-423: pack,
+ * MPI_Sendrecv, unpack) and reduces the norms with GlobalReduceMPI / MPI_Reduce
+ * (main.cpp:254-264).  Here the library packs and unpacks on the device and
+ * leaves the wire to a table of two operations.  With an exchange installed
+ * agx_iterate (and agx_halo_exchange) handle connections whose partner is on
+ * another rank, and the norms agx_iterate returns are the GLOBAL ones on every
+ * rank: l2 summed, linf the largest with its location, matrix_resid the sum of
+ * the ranks' values (what MPI_SUM of main.cpp:259 forms) -- the adapter drops
+ * its own reductions.
+ *   host_buffers = 0: slab pointers are device memory and the operations are
+ *     stream-ordered on hip_stream (the built-in RCCL transport);
+ *   host_buffers = 1: the library stages the slabs through pinned host memory
+ *     and calls the operations with host pointers after synchronising (an MPI,
+ *     socket or shared-memory transport: MPI_Sendrecv / MPI_Allgather fit).  */
+typedef struct agx_slab {
+  int32_t peer;              /* rank of the partner                          */
+  int32_t tag;               /* ordinal among the connections with this peer
+                              * (creation order): the same on both sides     */
+  int64_t count;             /* doubles to send and to receive               */
+  double *send, *recv;
+} agx_slab;
+typedef struct agx_exchange {
+  void *user;
+  /* complete (or enqueue on hip_stream) send[i] -> peer[i], recv[i] <- peer[i]
+   * for all n slabs of this rank; slabs come in connection-creation order */
+  int (*swap)(void *user, int n, const agx_slab *slabs, void *hip_stream);
+  /* every rank contributes `bytes` bytes at send; recv gets nranks * bytes,
+   * in rank order */
+  int (*allgather)(void *user, const void *send, void *recv, int64_t bytes,
+                   void *hip_stream);
+  int32_t nranks;
+  int32_t host_buffers;
+} agx_exchange;
+int agx_set_exchange(agx_ctx *ctx, const agx_exchange *ex);
+/* built-in transport: RCCL over xGMI, grouped ncclSend / ncclRecv per slab and
+ * one ncclAllGather for the norms, all on the library's stream (no host sync
+ * between pack and unpack).  id128: 128 bytes made by agx_rccl_unique_id on one
+ * rank and handed to the others by the host (MPI_Bcast in the reference's
+ * driver).  Call after agx_ctx_create, before agx_setup_finalize. */
+int agx_rccl_unique_id(void *id128);
+int agx_rccl_exchange_create(agx_ctx *ctx, const void *id128, int nranks, int rank);
+/* one ghost exchange as gridLevel::GetBoundaryConditions / lusgs::Relax place it:
+ * local connections + (with an exchange installed) remote ones */
+int agx_halo_exchange(agx_ctx *ctx, int what);
 
 /* ---- measurement helpers ----------------------------------------------- */
 /* average duration [ms] of the named kernel group since the last reset,

@@ -108,6 +108,21 @@ class hotPath {
     Check(AGX_SYM(conn_create)(ctx_, &conn, &id), "hotPath::AddConnection");
     return id;
   }
+  // multi-rank runs: the transport that stands where the reference has
+  // MPI_Sendrecv / MPI_Reduce (multiArray3d.hpp:830-866, main.cpp:254-264).  With
+  // one installed, Iterate exchanges the ghost slabs of connections to other ranks
+  // itself and returns norms already reduced over the ranks.
+  void SetExchange(const agx_exchange &ex) {
+    Check(AGX_SYM(set_exchange)(ctx_, &ex), "hotPath::SetExchange");
+  }
+  // the library's own RCCL transport; id128 from RcclUniqueId() on one rank,
+  // handed to the others by the host (MPI_Bcast)
+  static void RcclUniqueId(void *id128) {
+    Check(AGX_SYM(rccl_unique_id)(id128), "hotPath::RcclUniqueId");
+  }
+  void UseRccl(const void *id128, int numRanks, int rank) {
+    Check(AGX_SYM(rccl_exchange_create)(ctx_, id128, numRanks, rank), "hotPath::UseRccl");
+  }
   void Finalize() { Check(AGX_SYM(setup_finalize)(ctx_), "hotPath::Finalize"); }
   void UploadState(int block, const double *stateAos) {
     Check(AGX_SYM(state_upload)(ctx_, block, stateAos), "hotPath::UploadState");

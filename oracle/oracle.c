@@ -72,6 +72,8 @@ struct ora_ctx {
   conn_t conn[MAXCONN];
   /* derived gas constants */
   double gamma, cp, cv, mu_ref, k_nondim, scaling, prandtl;
+  agx_exchange ex;   /* multi-rank transport (host buffers) */
+  int have_ex;
 };
 
 /* ------------------------------------------------------------------------ */
@@ -1799,34 +1801,115 @@ int ora_halo_unpack(ora_ctx *c, int id, int what, const double *buf) {
   return 0;
 }
 
+/* ---- multi-rank: the same exchange table as the product library (always host
+ * buffers here), see include/aither_gfx950.h ---------------------------------- */
+typedef struct { double l2[8]; double mres, linf; int32_t block, i, j, k, eqn, pad;
+                 double fill[3]; } norm_record;     /* 128 bytes, as in agx_api.hip */
+int ora_set_exchange(ora_ctx *c, const agx_exchange *ex) {
+  if (!ex || !ex->swap || !ex->allgather || ex->nranks < 1)
+    return fail("set_exchange: swap, allgather and nranks are required");
+  c->ex = *ex;
+  c->have_ex = 1;
+  return 0;
+}
+int ora_rccl_unique_id(void *id128) { (void)id128; return fail("the CPU oracle has no RCCL"); }
+int ora_rccl_exchange_create(ora_ctx *c, const void *id, int n, int r) {
+  (void)c; (void)id; (void)n; (void)r;
+  return fail("the CPU oracle has no RCCL");
+}
+int ora_halo_exchange(ora_ctx *c, int what) {
+  if (ora_halo_swap_local(c, what)) return 1;
+  int nrem = 0;
+  for (int n = 0; n < c->nconn; ++n) nrem += my_side(c, &c->conn[n]) >= 0;
+  if (!nrem) return 0;
+  if (!c->have_ex) return fail("connections to other ranks need an exchange");
+  agx_slab *sl = (agx_slab *)malloc(sizeof(agx_slab) * nrem);
+  int *cid = (int *)malloc(sizeof(int) * nrem);
+  int q = 0;
+  for (int n = 0; n < c->nconn; ++n) {
+    const int s = my_side(c, &c->conn[n]);
+    if (s < 0) continue;
+    sl[q].peer = c->conn[n].c.rank[1 - s];
+    sl[q].tag = 0;      /* ordinal among the connections with this peer */
+    for (int m = 0; m < n; ++m) {
+      const int sm = my_side(c, &c->conn[m]);
+      if (sm >= 0 && c->conn[m].c.rank[1 - sm] == sl[q].peer) sl[q].tag++;
+    }
+    cid[q] = n;
+    sl[q].count = ora_halo_count(c, n, what);
+    sl[q].send = (double *)calloc(sl[q].count > 0 ? sl[q].count : 1, sizeof(double));
+    sl[q].recv = (double *)calloc(sl[q].count > 0 ? sl[q].count : 1, sizeof(double));
+    ora_halo_pack(c, n, what, sl[q].send);
+    ++q;
+  }
+  const int rc = c->ex.swap(c->ex.user, nrem, sl, NULL);
+  for (q = 0; q < nrem; ++q) {
+    if (!rc) ora_halo_unpack(c, cid[q], what, sl[q].recv);
+    free(sl[q].send);
+    free(sl[q].recv);
+  }
+  free(sl);
+  free(cid);
+  return rc ? fail("the exchange's swap operation failed") : 0;
+}
+
 /* mgSolution::Iterate mgSolution.cpp:246-269, gridLevel::GetBoundaryConditions
  * gridLevel.cpp:287-319, mgSolution::ImplicitUpdate :209-244, lusgs::Relax
- * linearSolver.cpp:430-470, dplur::Relax :509-535 */
+ * linearSolver.cpp:430-470, dplur::Relax :509-535; with an exchange installed the
+ * norms are reduced over the ranks as main.cpp:254-264 does */
 int ora_iterate(ora_ctx *c, int mm, double cfl, double *l2, agx_linf *linf,
                 double *matrix_resid) {
-  for (int n = 0; n < c->nconn; ++n)
-    if (my_side(c, &c->conn[n]) >= 0)
-      return fail("iterate: remote connections need the phase API");
+  double l2_in[NEQ];
+  for (int e = 0; e < NEQ; ++e) l2_in[e] = l2[e];
+  if (!c->have_ex)
+    for (int n = 0; n < c->nconn; ++n)
+      if (my_side(c, &c->conn[n]) >= 0)
+        return fail("iterate: connections to other ranks need an exchange or the phase API");
   if (ora_phase_bc_faces(c)) return 1;
-  if (ora_halo_swap_local(c, AGX_HALO_STATE)) return 1;
+  if (ora_halo_exchange(c, AGX_HALO_STATE)) return 1;
   if (ora_phase_bc_edges(c)) return 1;
   if (ora_phase_residual(c, mm, cfl)) return 1;
   *matrix_resid = 0.0;
   if (c->cfg.time_integration >= AGX_TIME_IMPLICIT_EULER) {
     ora_phase_implicit_begin(c);
     for (int s = 0; s < c->cfg.matrix_sweeps; ++s) {
-      ora_halo_swap_local(c, AGX_HALO_UPDATE);
+      if (ora_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
       ora_phase_relax_forward(c, s);
       if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
-        ora_halo_swap_local(c, AGX_HALO_UPDATE);
+        if (ora_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
         ora_phase_relax_backward(c, s);
       }
     }
-    ora_halo_swap_local(c, AGX_HALO_UPDATE);
+    if (ora_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
     ora_phase_matrix_residual(c, matrix_resid);
     ora_phase_implicit_update(c, mm, l2, linf);
   } else {
     ora_phase_explicit_update(c, mm, l2, linf);
+  }
+  if (c->have_ex && c->ex.nranks > 1) {
+    const int nr = c->ex.nranks;
+    norm_record mine, *all = (norm_record *)calloc(nr, sizeof(norm_record));
+    memset(&mine, 0, sizeof mine);
+    for (int e = 0; e < NEQ; ++e) mine.l2[e] = l2[e] - l2_in[e];
+    mine.mres = *matrix_resid;
+    mine.linf = linf->linf; mine.block = linf->block; mine.i = linf->i; mine.j = linf->j;
+    mine.k = linf->k; mine.eqn = linf->eqn;
+    if (c->ex.allgather(c->ex.user, &mine, all, (int64_t)sizeof mine, NULL)) {
+      free(all);
+      return fail("the exchange's allgather operation failed");
+    }
+    double mres = 0.0;
+    for (int e = 0; e < NEQ; ++e) l2[e] = l2_in[e];
+    for (int r = 0; r < nr; ++r) {
+      for (int e = 0; e < NEQ; ++e) l2[e] += all[r].l2[e];
+      mres += all[r].mres;
+      if (all[r].linf > linf->linf) {
+        linf->linf = all[r].linf; linf->block = all[r].block; linf->i = all[r].i;
+        linf->j = all[r].j; linf->k = all[r].k; linf->eqn = all[r].eqn;
+      }
+    }
+    *matrix_resid = mres;
+    free(all);
   }
   return 0;
 }

@@ -51,6 +51,10 @@ int ora_halo_swap_local(ora_ctx *ctx, int what);
 int64_t ora_halo_count(ora_ctx *ctx, int conn_id, int what);
 int ora_halo_pack(ora_ctx *ctx, int conn_id, int what, double *buf);
 int ora_halo_unpack(ora_ctx *ctx, int conn_id, int what, const double *buf);
+int ora_set_exchange(ora_ctx *ctx, const agx_exchange *ex);
+int ora_rccl_unique_id(void *id128);
+int ora_rccl_exchange_create(ora_ctx *ctx, const void *id128, int nranks, int rank);
+int ora_halo_exchange(ora_ctx *ctx, int what);
 int ora_timing_enable(ora_ctx *ctx, int on);
 int ora_timing_get(ora_ctx *ctx, int group, double *avg_ms, int64_t *launches);
 int ora_timing_reset(ora_ctx *ctx);

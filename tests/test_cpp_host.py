@@ -33,7 +33,7 @@ def write_case_file(case, path, n_steps):
     d = case.deck
     cfg = _b.config_struct(case)
     with open(path, "wb") as f:
-        f.write(struct.pack("<7i", 0x31584741, len(case.blocks), len(case.connections),
+        f.write(struct.pack("<7i", 0x32584741, len(case.blocks), len(case.connections),
                             d.nonlinear_iterations, n_steps,
                             int(d.need_to_store_time_n()),
                             int(d.is_multilevel_in_time())))
@@ -41,7 +41,8 @@ def write_case_file(case, path, n_steps):
         f.write(bytes(cfg))
         for gb, blk in enumerate(case.blocks):
             g = blk.geom
-            f.write(struct.pack("<6i", g.ni, g.nj, g.nk, g.ng, blk.parent, blk.global_pos))
+            f.write(struct.pack("<7i", g.ni, g.nj, g.nk, g.ng, blk.parent, blk.global_pos,
+                                int(blk.rank or 0)))
             for a in (g.farea["i"].a, g.farea["j"].a, g.farea["k"].a, g.vol.a,
                       g.center.a, g.width["i"].a, g.width["j"].a, g.width["k"].a,
                       g.wall_dist.a):
@@ -57,7 +58,10 @@ def write_case_file(case, path, n_steps):
             f.write(bytes(cs))
 
 
-def read_output(case, path, n_steps):
+def read_output(case, path, n_steps, rank=None):
+    """rank: read <path>.<rank>, which holds only that rank's blocks"""
+    if rank is not None:
+        path = f"{path}.{rank}"
     n_eq, nonlin = 5, case.deck.nonlinear_iterations
     raw = open(path, "rb").read()
     rec = n_eq * 8 + 16 + 20
@@ -70,6 +74,8 @@ def read_output(case, path, n_steps):
         off += rec
     states = []
     for blk in case.blocks:
+        if rank is not None and blk.rank != rank:
+            continue
         n = blk.state.size
         states.append(np.frombuffer(raw, "<f8", n, off).reshape(blk.state.shape).copy())
         off += n * 8
@@ -132,3 +138,53 @@ def test_cpp_host_gpu_vs_oracle(tmp_path, name):
         assert rel_err(l2g[None, :], l2o[None, :]) < RTOL
     for a, b in zip(sg, so):
         assert rel_err(a[ng:-ng, ng:-ng, ng:-ng], b[ng:-ng, ng:-ng, ng:-ng]) < RTOL
+
+
+MR_KINDS = {
+    "rk4": dict(time_integration="rk4", cfl=0.5),
+    "lusgs": dict(time_integration="implicitEuler", matrix_solver="lusgs", cfl=5.0),
+    "dplur": dict(inviscid_flux="ausm", limiter="none", time_integration="implicitEuler",
+                  matrix_solver="dplur", matrix_sweeps=4, cfl=5.0),
+}
+
+
+def _multirank(driver, oracle, tmp_path, kind, world, exact):
+    """hotPath::Iterate with an exchange installed, one process per rank joined by
+    socket pairs, against the single-process oracle."""
+    build_drivers()
+    kw = MR_KINDS[kind]
+    case = synthetic.stacked_blocks_case((10, 6, 5), nblocks=world, axis="k", stretch=1.1,
+                                         ranks=list(range(world)), **kw)
+    cf, of = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
+    write_case_file(case, cf, 2)
+    subprocess.check_call([os.path.join(CPP, driver), cf, of, str(world)], timeout=600)
+    one = synthetic.stacked_blocks_case((10, 6, 5), nblocks=world, axis="k", stretch=1.1, **kw)
+    ref = Solver(oracle, one)
+    for nn in range(2):
+        ref.step(nn)
+    l2ref = np.array([h["l2"] ** 2 for h in ref.history])
+    ng = case.ng
+    for r in range(world):
+        hist, states = read_output(case, of, 2, rank=r)
+        l2 = np.array([h[0] for h in hist])
+        a = states[0][ng:-ng, ng:-ng, ng:-ng]
+        b = ref.download("state", r)[ng:-ng, ng:-ng, ng:-ng]
+        if exact:
+            assert np.allclose(l2, l2ref, rtol=1e-12) and np.array_equal(a, b)
+        else:
+            assert rel_err(l2, l2ref) < RTOL and rel_err(a, b) < RTOL
+    ref.close()
+
+
+@pytest.mark.parametrize("kind,world", [("rk4", 2), ("lusgs", 2), ("dplur", 3)])
+def test_cpp_multirank_oracle(oracle, tmp_path, kind, world):
+    _multirank("host_parity_ora", oracle, tmp_path, kind, world, exact=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world", [("rk4", 2), ("lusgs", 2), ("dplur", 3)])
+def test_cpp_multirank_gpu(oracle, tmp_path, kind, world):
+    """the same with libaither_gfx950.so: the ranks share cuda:0, the slabs are
+    staged through pinned host buffers (host_buffers = 1)"""
+    _multirank("host_parity_agx", oracle, tmp_path, kind, world, exact=False)
+
