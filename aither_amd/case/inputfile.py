@@ -196,8 +196,8 @@ class InputDeck:
             bad.append(f"matrixSolver {self.matrix_solver}")
         if self.inv_flux_jac != "rusanov":
             bad.append(f"inviscidFluxJacobian {self.inv_flux_jac}")
-        if self.viscous_face_reconstruction != "central":
-            bad.append("centralFourth")
+        if self.viscous_face_reconstruction not in ("central", "centralFourth"):
+            bad.append(f"viscousFaceReconstruction {self.viscous_face_reconstruction}")
         if bad:
             raise NotImplementedError(
                 "outside the accelerated hot path: " + ", ".join(bad))

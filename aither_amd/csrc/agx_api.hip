@@ -803,9 +803,12 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
   if (cfg->inv_flux_jacobian != AGX_JACOBIAN_RUSANOV)
     return fail("inv_flux_jacobian %d: only rusanov (RusanovScalarOffDiagonal, "
                 "fluxJacobian.cpp:122) is built; approximateRoe is not", cfg->inv_flux_jacobian);
-  if (cfg->viscous_recon != AGX_VISC_RECON_CENTRAL)
-    return fail("viscous_recon %d: only central (FaceReconCentral, reconstruction.hpp:315) "
-                "is built; centralFourth is not", cfg->viscous_recon);
+  if (cfg->viscous_recon != AGX_VISC_RECON_CENTRAL &&
+      cfg->viscous_recon != AGX_VISC_RECON_CENTRAL_4TH)
+    return fail("viscous_recon %d is not one of central / centralFourth", cfg->viscous_recon);
+  if (cfg->viscous_recon == AGX_VISC_RECON_CENTRAL_4TH && cfg->n_ghost < 2)
+    return fail("centralFourth needs two ghost layers (input::NumberGhostLayers, "
+                "input.cpp:1127-1143)");
   if (cfg->matrix_solver != AGX_SOLVER_LUSGS && cfg->matrix_solver != AGX_SOLVER_DPLUR)
     return fail("matrix_solver %d: the block-matrix solvers (blusgs, bdplur) are not built",
                 cfg->matrix_solver);
@@ -957,7 +960,8 @@ int agx_setup_finalize(agx_ctx* c) {
     max_parts = std::max(max_parts, (long)g.x * g.y * g.z);
     march_parts += march_plan(c, blk.d).nparts;
     if (blk.d.d2.base)    // k_matrix_resid_d2: one partial per 256 plane positions
-      max_parts = std::max(max_parts, (((long)blk.d.d2.Pi * blk.d.d2.Pj + 255) / 256) * blk.d.nk);
+      max_parts = std::max(max_parts,
+                           8 * (((((long)blk.d.d2.Pi * blk.d.d2.Pj + 255) / 256) + 7) / 8) * blk.d.nk);
   }
   max_parts = std::max(max_parts, march_parts);
   for (auto& k : c->conns) {
@@ -1184,9 +1188,12 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
     }
     Timer t(c, G_VISC);
     for (auto& blk : c->blocks)
-      if (c->visc_gather) {
+      if (c->visc_gather || c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH) {
+        // (centralFourth reaches two cells to either side of a face: served by the
+        // one-thread-per-cell form, whose stencil comes straight from the planes)
         hipLaunchKernelGGL(k_visc_residual, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
-                           0, c->stream, blk.d, c->gas, c->sp, cfl);
+                           0, c->stream, blk.d, c->gas, c->sp, cfl,
+                           c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH ? 1 : 0);
       } else {
         const BlockDev& vb = blk.d;
         if (c->visc_march || (double)vb.nplane * 8.0 >= 4294967296.0) {
@@ -1280,10 +1287,12 @@ int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       const BlockDev& b = c->blocks[n].d;
       if (b.d2.base) {
-        const dim3 grid(((long)b.d2.Pi * b.d2.Pj + 255) / 256, b.nk);
-        hipLaunchKernelGGL(k_matrix_resid_d2, grid, dim3(256), 0, c->stream, b, c->gas,
-                           c->sp, c->partials);
-        if (reduce_norms(c, n, (long)grid.x * grid.y)) return 1;
+        // (position chunk, k) pairs dealt to the XCDs column by column, see the kernel
+        const long nchunk = ((long)b.d2.Pi * b.d2.Pj + 255) / 256;
+        const long nwg = 8 * ((nchunk + 7) / 8) * b.nk;
+        hipLaunchKernelGGL(k_matrix_resid_d2, dim3((unsigned)nwg), dim3(256), 0, c->stream, b,
+                           c->gas, c->sp, c->partials);
+        if (reduce_norms(c, n, nwg)) return 1;
         continue;
       }
       const dim3 grid = cell_grid(b, CELL_BLOCK);

@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void uvwt(const BlockDev& b, const GasDev& g, long q,
 }
 // viscous flux * |A| through the lower d-face of cell index qU (cells qL|qU)
 __device__ __forceinline__ void visc_face(const BlockDev& b, const GasDev& g,
-                                          int d, long qU, double* f) {
+                                          int d, long qU, double* f, bool fourth = false) {
   const long sd = b.stride(d);
   const long qL = qU - sd;
   double grad[3][4];          // [derivative direction][u, v, w, T]
@@ -1093,14 +1093,35 @@ __device__ __forceinline__ void visc_face(const BlockDev& b, const GasDev& g,
   // FaceReconCentral reconstruction.hpp:315-328: coeffs = LagrangeCoeff(
   // {wU, wD}, 1, 0, 0) = {wD, wU} / (wU + wD) and the reference forms
   // coeffs[0] * varD + coeffs[1] * varU (the wider cell gets the larger weight)
-  const double wU = b.wid[d][qL], wD = b.wid[d][qU];
-  const double cD = wD / (wU + wD), cU = wU / (wU + wD);
-  double sL[AGX_NEQ], sU[AGX_NEQ], sf[AGX_NEQ];
-  load5(b.state, qL, sL);
-  load5(b.state, qU, sU);
+  double sf[AGX_NEQ], muf;
+  if (fourth) {
+    // FaceReconCentral4th reconstruction.hpp:335-379, LagrangeCoeff(w, 3, 1, 1);
+    // state and viscosity of the four cells around the face (procBlock.cpp:1325-1346)
+    const long qs[4] = {qL - sd, qL, qU, qU + sd};
+    const double w4[4] = {b.wid[d][qs[0]], b.wid[d][qs[1]], b.wid[d][qs[2]], b.wid[d][qs[3]]};
+    double cf[4];
+    lagrange_coeff<3>(w4, 1, 1, cf);
+    muf = 0.0;
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) sf[e] = cD * sU[e] + cU * sL[e];
-  const double muf = cD * viscosity(g, vU[3]) + cU * viscosity(g, vL[3]);
+    for (int e = 0; e < AGX_NEQ; ++e) sf[e] = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      double s4[AGX_NEQ];
+      load5(b.state, qs[m], s4);
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) sf[e] += cf[m] * s4[e];
+      muf += cf[m] * viscosity(g, temperature(g, s4));
+    }
+  } else {
+    const double wU = b.wid[d][qL], wD = b.wid[d][qU];
+    const double cD = wD / (wU + wD), cU = wU / (wU + wD);
+    double sL[AGX_NEQ], sU[AGX_NEQ];
+    load5(b.state, qL, sL);
+    load5(b.state, qU, sU);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) sf[e] = cD * sU[e] + cU * sL[e];
+    muf = cD * viscosity(g, vU[3]) + cU * viscosity(g, vL[3]);
+  }
   double n[4];
   load_area(b, d, qU, n);
   const double mu = g.scaling * muf;
@@ -1124,7 +1145,7 @@ __device__ __forceinline__ void visc_face(const BlockDev& b, const GasDev& g,
 }
 
 __global__ void __launch_bounds__(256)
-k_visc_residual(BlockDev b, GasDev g, SolverDev sp, double cfl) {
+k_visc_residual(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
@@ -1142,10 +1163,10 @@ k_visc_residual(BlockDev b, GasDev g, SolverDev sp, double cfl) {
   for (int d = 0; d < 3; ++d) {
     const long s = b.stride(d);
     double f[AGX_NEQ];
-    visc_face(b, g, d, q, f);
+    visc_face(b, g, d, q, f, fourth != 0);
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) res[e] += f[e];
-    visc_face(b, g, d, q + s, f);
+    visc_face(b, g, d, q + s, f, fourth != 0);
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) res[e] -= f[e];
     // ViscCellSpectralRadius spectralRadius.hpp:94-124

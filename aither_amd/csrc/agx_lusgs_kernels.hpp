@@ -630,12 +630,20 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
 __global__ void __launch_bounds__(256)
 k_matrix_resid_d2(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
   const D2Dev& z = b.d2;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
+  // 1-D grid of (position chunk, k) pairs.  Workgroup n runs on XCD n % 8 (each
+  // with its own L2): give every XCD whole columns of chunks and walk k fastest,
+  // so that a workgroup finds planes k-1 and k of its chunk in the L2 its
+  // predecessor on the same XCD just filled (the plane set of one k is ~20 MB).
+  const int nchunk = (z.Pi * z.Pj + 255) / 256;
+  const int xcd = blockIdx.x % 8, m = blockIdx.x / 8;
+  const int per = (nchunk + 7) / 8;                 // chunks per XCD
+  const int chunk = xcd + 8 * (m / b.nk), k = m % b.nk;
+  const int t = chunk * 256 + threadIdx.x;
   const bool visc = sp.viscous != 0;
   double r[AGX_NEQ] = {0, 0, 0, 0, 0};
   bool active = false;
-  if (t < z.Pi * z.Pj) {
+  (void)per;
+  if (chunk < nchunk && t < z.Pi * z.Pj) {
     const int ij = z.ij_of_pos[t];
     const int ie = ij & 0xffff, je = ij >> 16;
     const int i = ie - b.ng, j = je - b.ng;
@@ -674,8 +682,7 @@ k_matrix_resid_d2(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
       for (int e = 0; e < AGX_NEQ; ++e) r[e] = -(xv[e] * a - acc[e] - bv[e]);
     }
   }
-  const long bid = (long)blockIdx.y * gridDim.x + blockIdx.x;
-  norm_block_reduce(r, 0, active, partials + bid);
+  norm_block_reduce(r, 0, active, partials + blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------

@@ -262,19 +262,6 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { sh[ty][l][VS_FJ + c] = fj[c]; racc[c] += fj[c]; }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- request the plane that enters the window next step (in flight during
-    // the k-face) ----
-    double nS[4], nR, nMU, nAI[3], nAJ[3], nAK[3], nAIp[3], nAJp[3];
-    const unsigned qn = qc + (unsigned)(kk + 1) * sk;            // plane kk+1 (always valid)
-    const unsigned qn2 = qc + (unsigned)min(kk + 2, kcmax) * sk; // cells of plane kk+2
-    ld_state(kk + 2, nS, nR, nMU);
-    ld_avec(0, qn2, nAI);
-    ld_avec(1, qn2, nAJ);
-    ld_avec(2, qc + (unsigned)min(kk + 3, kfmax) * sk, nAK);
-    ld_avec(0, qn + 8, nAIp);
-    ld_avec(1, qn + sj, nAJp);
-    const double nV = b.ldb(PL_VOL, qn2), nWK = b.ldb(PL_WID + 2, qn2);
-    const double nwi = b.ldb(PL_WID + 0, qn), nwj = b.ldb(PL_WID + 1, qn);
     // ---- upper k-face: cells (i,j,k) | (i,j,k+1) ----
     const double R0 = sh[ty][l][VS_RHO], MU0 = sh[ty][l][VS_MU], V0 = sh[ty][l][VS_VOL];
     if (own) {
@@ -289,6 +276,20 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
               WK0, WK1, fk_up);
     }
     __builtin_amdgcn_sched_barrier(0);
+    // ---- request the plane that enters the window next step (after the faces:
+    // together with their operands it does not fit the register file; in flight
+    // during the barrier and the residual update) ----
+    double nS[4], nR, nMU, nAI[3], nAJ[3], nAK[3], nAIp[3], nAJp[3];
+    const unsigned qn = qc + (unsigned)(kk + 1) * sk;            // plane kk+1 (always valid)
+    const unsigned qn2 = qc + (unsigned)min(kk + 2, kcmax) * sk; // cells of plane kk+2
+    ld_state(kk + 2, nS, nR, nMU);
+    ld_avec(0, qn2, nAI);
+    ld_avec(1, qn2, nAJ);
+    ld_avec(2, qc + (unsigned)min(kk + 3, kfmax) * sk, nAK);
+    ld_avec(0, qn + 8, nAIp);
+    ld_avec(1, qn + sj, nAJp);
+    const double nV = b.ldb(PL_VOL, qn2), nWK = b.ldb(PL_WID + 2, qn2);
+    const double nwi = b.ldb(PL_WID + 0, qn), nwj = b.ldb(PL_WID + 1, qn);
     __syncthreads();                           // all faces done: the windows may rotate
     if (own && !pre) {
       const unsigned q = qc + (unsigned)kk * sk;

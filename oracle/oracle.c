@@ -1155,12 +1155,27 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
         calc_grads(b, d, i, j, k, velGrad, tGrad);
         const long cL = CI(b, i - o[0], j - o[1], k - o[2]);
         const long cU = CI(b, i, j, k);
-        double cf[2];
-        central_coeffs(b->wid[d][cL], b->wid[d][cU], cf);
-        double st[NEQ];
-        for (int e = 0; e < NEQ; ++e)
-          st[e] = cf[0] * b->state[NEQ * cU + e] + cf[1] * b->state[NEQ * cL + e];
-        const double mu = cf[0] * b->visc[cU] + cf[1] * b->visc[cL];
+        double st[NEQ], mu;
+        if (c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH) {
+          /* FaceReconCentral4th reconstruction.hpp:335-379 with
+           * LagrangeCoeff(cellWidth, 3, 1, 1); procBlock.cpp:1325-1346 */
+          const long cU2 = CI(b, i - 2 * o[0], j - 2 * o[1], k - 2 * o[2]);
+          const long cD2 = CI(b, i + o[0], j + o[1], k + o[2]);
+          const double w4[4] = {b->wid[d][cU2], b->wid[d][cL], b->wid[d][cU], b->wid[d][cD2]};
+          double cf4[4];
+          lagrange_coeff(w4, 3, 1, 1, cf4);
+          for (int e = 0; e < NEQ; ++e)
+            st[e] = cf4[0] * b->state[NEQ * cU2 + e] + cf4[1] * b->state[NEQ * cL + e] +
+                    cf4[2] * b->state[NEQ * cU + e] + cf4[3] * b->state[NEQ * cD2 + e];
+          mu = cf4[0] * b->visc[cU2] + cf4[1] * b->visc[cL] + cf4[2] * b->visc[cU] +
+               cf4[3] * b->visc[cD2];
+        } else {
+          double cf[2];
+          central_coeffs(b->wid[d][cL], b->wid[d][cU], cf);
+          for (int e = 0; e < NEQ; ++e)
+            st[e] = cf[0] * b->state[NEQ * cU + e] + cf[1] * b->state[NEQ * cL + e];
+          mu = cf[0] * b->visc[cU] + cf[1] * b->visc[cL];
+        }
         const double *area = b->fa[d] + 4 * FI(b, d, i, j, k);
         double f[NEQ];
         visc_flux(c, velGrad, tGrad, area, st, mu, f);

@@ -247,6 +247,16 @@ CASES = {
     "visc_heatflux_wall_lusgs": dict(
         n=(10, 9, 8), stretch=1.15, bcs=WALL_HEATFLUX, equation_set="navierStokes",
         time_integration="implicitEuler", matrix_solver="lusgs", cfl=10.0),
+    # viscousFaceReconstruction: centralFourth (FaceReconCentral4th
+    # reconstruction.hpp:335-379): four-cell face state and viscosity
+    "visc_central4th_lusgs": dict(
+        n=(11, 10, 9), stretch=1.15, bcs=WALL_J, equation_set="navierStokes",
+        viscous_face_reconstruction="centralFourth",
+        time_integration="implicitEuler", matrix_solver="lusgs", cfl=10.0),
+    "visc_central4th_weno_rk4": dict(
+        n=(9, 10, 8), stretch=1.2, bcs=WALL_ISO, equation_set="navierStokes",
+        face_reconstruction="weno", limiter="none",
+        viscous_face_reconstruction="centralFourth", time_integration="rk4", cfl=0.3),
 }
 
 
