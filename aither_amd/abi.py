@@ -21,7 +21,8 @@ BC = {"slipWall": 0, "viscousWall": 1, "characteristic": 2, "inlet": 3,
       "pressureOutlet": 7, "interblock": 8, "periodic": 9}
 FIELD = {"state": 0, "residual": 1, "dt": 2, "spec_radius": 3, "cons_n": 4,
          "update": 5, "diagonal": 6, "temperature": 7, "viscosity": 8,
-         "cons_nm1": 9}
+         "cons_nm1": 9, "vel_grad": 10, "temp_grad": 11, "dens_grad": 12,
+         "press_grad": 13}
 HALO_STATE, HALO_UPDATE = 0, 1
 
 c_dp = C.POINTER(C.c_double)

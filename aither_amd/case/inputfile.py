@@ -194,7 +194,7 @@ class InputDeck:
             bad.append("multigrid")
         if self.matrix_solver not in ("lusgs", "dplur"):
             bad.append(f"matrixSolver {self.matrix_solver}")
-        if self.inv_flux_jac != "rusanov":
+        if self.inv_flux_jac not in ("rusanov", "approximateRoe"):
             bad.append(f"inviscidFluxJacobian {self.inv_flux_jac}")
         if self.viscous_face_reconstruction not in ("central", "centralFourth"):
             bad.append(f"viscousFaceReconstruction {self.viscous_face_reconstruction}")

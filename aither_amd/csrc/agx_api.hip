@@ -453,7 +453,10 @@ bool can_fuse(const agx_ctx* c) {
 
 // the D2 LU-SGS path (agx_lusgs.hpp) serves scalar LU-SGS unless AGX_LUSGS=plane
 bool use_d2(const agx_ctx* c) {
-  return c->sp.implicit && c->cfg.matrix_solver == AGX_SOLVER_LUSGS && c->lusgs_mode == 1;
+  // (the Roe off-diagonal needs the state on both sides of a face: served by the
+  // hyperplane-per-launch form on the SoA planes)
+  return c->sp.implicit && c->cfg.matrix_solver == AGX_SOLVER_LUSGS && c->lusgs_mode == 1 &&
+         c->cfg.inv_flux_jacobian == AGX_JACOBIAN_RUSANOV;
 }
 // One LU-SGS half sweep over a block, one launch: a workgroup per k-plane marches
 // the plane's diagonals, the planes follow each other one step apart (k_lusgs_kp).
@@ -548,7 +551,7 @@ int lusgs_kp_variant(agx_ctx* c, Block& blk, int full) {
 
 int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full) {
   const BlockDev& b = blk.d;
-  if (c->lusgs_mode == 0) {
+  if (!b.d2.base) {
     const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
     const int nplanes = b.ni + b.nj + b.nk - 2;
     for (int t = 0; t < nplanes; ++t) {
@@ -800,9 +803,14 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
   if (cfg->turbulence_model != AGX_TURB_NONE)
     return fail("turbulence_model %d is not built (laminar / inviscid only)",
                 cfg->turbulence_model);
-  if (cfg->inv_flux_jacobian != AGX_JACOBIAN_RUSANOV)
-    return fail("inv_flux_jacobian %d: only rusanov (RusanovScalarOffDiagonal, "
-                "fluxJacobian.cpp:122) is built; approximateRoe is not", cfg->inv_flux_jacobian);
+  if (cfg->inv_flux_jacobian != AGX_JACOBIAN_RUSANOV &&
+      cfg->inv_flux_jacobian != AGX_JACOBIAN_APPROX_ROE)
+    return fail("inv_flux_jacobian %d is not one of rusanov / approximateRoe",
+                cfg->inv_flux_jacobian);
+  if (cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE && cfg->is_viscous)
+    return fail("approximateRoe with viscous terms is not built: the reference hands dist and "
+                "f1 to RoeOffDiagonal in swapped order (fluxJacobian.cpp:232 vs :240) and "
+                "divides by f1 = 0 in laminar runs");
   if (cfg->viscous_recon != AGX_VISC_RECON_CENTRAL &&
       cfg->viscous_recon != AGX_VISC_RECON_CENTRAL_4TH)
     return fail("viscous_recon %d is not one of central / centralFourth", cfg->viscous_recon);
@@ -828,6 +836,7 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
   // input::MatrixRequiresInitialization input.cpp:1120-1125
   sp.requires_init = cfg->matrix_solver == AGX_SOLVER_DPLUR || cfg->matrix_sweeps > 1;
   sp.time_integration = cfg->time_integration;
+  sp.roe_jacobian = cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE;
   c->have_cfg = true;
   return 0;
 }
@@ -1102,6 +1111,23 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
   if (field == AGX_FIELD_UPDATE && b.d.d2.base && d2_x_copy(c, b, 0)) return 1;
+  if (field >= AGX_FIELD_VEL_GRAD && field <= AGX_FIELD_PRESS_GRAD) {
+    // cell-centre gradients: formed on demand into a temporary (an output path)
+    const long ncell = (long)b.d.ni * b.d.nj * b.d.nk;
+    double* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, sizeof(double) * 18 * ncell));
+    hipLaunchKernelGGL(k_cell_grads, cell_grid(b.d, CELL_BLOCK), CELL_BLOCK, 0, c->stream, b.d,
+                       c->gas, tmp);
+    HIPCHK(hipGetLastError());
+    const int off = field == AGX_FIELD_VEL_GRAD ? 0 : 9 + 3 * (field - AGX_FIELD_TEMP_GRAD);
+    const int nc = field == AGX_FIELD_VEL_GRAD ? 9 : 3;
+    // strided device -> host copy of the requested columns
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(double) * nc, tmp + off, sizeof(double) * 18,
+                            sizeof(double) * nc, ncell, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(tmp));
+    return 0;
+  }
   if (field == AGX_FIELD_TEMPERATURE || field == AGX_FIELD_VISCOSITY) {
     // formed on demand from the current state into a scratch plane (the x_old
     // plane of DPLUR: rebuilt at the start of every implicit iteration)

@@ -426,13 +426,23 @@ __device__ __forceinline__ double visc_term(const GasDev& g, double mu) {
 
 // RusanovScalarOffDiagonal fluxJacobian.cpp:122-162 with FaceSpectralRadius
 // spectralRadius.hpp:182-203 and ConvectiveFluxUpdate inviscidFlux.hpp:544-562
+// diag != nullptr selects RoeOffDiagonal (fluxJacobian.cpp:240-291, inviscid): the
+// change of the Roe flux between the neighbour and the cell `diag`
 __device__ __forceinline__ void off_diagonal(const GasDev& g, bool viscous,
                                              const double* s, const double* du,
                                              const double* area, double mu,
                                              double dist, bool positive,
-                                             double* out) {
+                                             double* out, const double* diag = nullptr) {
   double su[AGX_NEQ], fo[AGX_NEQ], fn[AGX_NEQ];
   update_prim_with_cons(g, s, du, su);
+  if (diag) {
+    roe_flux(g, s, diag, area, fo);
+    if (positive) roe_flux(g, su, diag, area, fn);
+    else roe_flux(g, diag, su, area, fn);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) out[e] = area[3] * (fn[e] - fo[e]);
+    return;
+  }
   phys_flux(g, s, area, fo);
   phys_flux(g, su, area, fn);
   double sr = 0.5 * area[3] * (fabs(dot3(s + 1, area)) + sound_speed(g, s));

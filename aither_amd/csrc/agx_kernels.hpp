@@ -96,6 +96,7 @@ struct SlabDev {               // compact view used by the marching kernel
 struct SolverDev {   // scalar run-time parameters of agx_config
   double kappa, theta, zeta, relax, dual_time_cfl, dt_fixed, visc_cfl_coeff;
   int viscous, implicit, bdf2, requires_init, time_integration;
+  int roe_jacobian;    // inviscidFluxJacobian: approximateRoe (RoeOffDiagonal)
 };
 
 __device__ __forceinline__ void load5(double* const* p, long q, double* s) {
@@ -1673,7 +1674,9 @@ __device__ __forceinline__ void add_off_diag(const BlockDev& b, const GasDev& g,
       dist = dot3(v, area);
       mu = viscosity(g, temperature(g, sn));
     }
-    off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od);
+    double sd[AGX_NEQ];
+    if (sp.roe_jacobian) load5(b.state, q, sd);
+    off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od, sp.roe_jacobian ? sd : nullptr);
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) acc[e] += sign * od[e];
   }
@@ -1796,6 +1799,74 @@ k_matrix_resid(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
   }
   const long bid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   norm_block_reduce(r, 0, active, partials + bid);
+}
+
+// Cell-centre gradients for output (velocityGrad_, temperatureGrad_, densityGrad_,
+// pressureGrad_): one sixth of each of the six Green-Gauss face gradients of the
+// cell (procBlock.cpp:1397-1449, CalcGradsI/J/K :5173-5786), six fields u, v, w,
+// T, rho, p.  Formed on demand; one thread per cell straight from the planes (an
+// output step, not the iteration).  out: [cell][18], physical cells, i fastest.
+__device__ __forceinline__ double grad_field(const BlockDev& b, const GasDev& g, long q, int f) {
+  if (f < 3) return b.state[1 + f][q];
+  if (f == 4) return b.state[0][q];
+  if (f == 5) return b.state[4][q];
+  return b.state[4][q] / (b.state[0][q] * g.R);
+}
+__device__ inline void face_grad6(const BlockDev& b, const GasDev& g, int d, long qU,
+                                  double (*g6)[6]) {
+  const long sd = b.stride(d), qL = qU - sd;
+  double au[3][3], al[3][3];
+  {
+    double a0[3], a1[3], a2[3];
+    area_vec(b, d, qU, a0); area_vec(b, d, qU + sd, a1); area_vec(b, d, qU - sd, a2);
+    for (int r = 0; r < 3; ++r) { au[d][r] = 0.5 * (a0[r] + a1[r]); al[d][r] = 0.5 * (a0[r] + a2[r]); }
+  }
+  for (int t = 0; t < 3; ++t) {
+    if (t == d) continue;
+    const long st = b.stride(t);
+    double a0[3], a1[3];
+    area_vec(b, t, qU + st, a0); area_vec(b, t, qL + st, a1);
+    for (int r = 0; r < 3; ++r) au[t][r] = 0.5 * (a0[r] + a1[r]);
+    area_vec(b, t, qU, a0); area_vec(b, t, qL, a1);
+    for (int r = 0; r < 3; ++r) al[t][r] = 0.5 * (a0[r] + a1[r]);
+  }
+  const double inv_vol = 1.0 / (0.5 * (b.vol[qL] + b.vol[qU]));
+  for (int f = 0; f < 6; ++f) {
+    double vu[3], vl[3];
+    const double fL = grad_field(b, g, qL, f), fU = grad_field(b, g, qU, f);
+    vl[d] = fL; vu[d] = fU;
+    for (int t = 0; t < 3; ++t) {
+      if (t == d) continue;
+      const long st = b.stride(t);
+      vu[t] = 0.25 * (fL + fU + grad_field(b, g, qU + st, f) + grad_field(b, g, qL + st, f));
+      vl[t] = 0.25 * (fL + fU + grad_field(b, g, qU - st, f) + grad_field(b, g, qL - st, f));
+    }
+    for (int r = 0; r < 3; ++r)
+      g6[r][f] = (vu[0] * au[0][r] - vl[0] * al[0][r] + vu[1] * au[1][r] - vl[1] * al[1][r] +
+                  vu[2] * au[2][r] - vl[2] * al[2][r]) * inv_vol;
+  }
+}
+__global__ void __launch_bounds__(256) k_cell_grads(BlockDev b, GasDev g, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  double acc[18];
+  for (int n = 0; n < 18; ++n) acc[n] = 0.0;
+  for (int d = 0; d < 3; ++d)
+    for (int up = 0; up < 2; ++up) {
+      double g6[3][6];
+      face_grad6(b, g, d, q + (up ? b.stride(d) : 0), g6);
+      for (int r = 0; r < 3; ++r) {
+        for (int f = 0; f < 3; ++f) acc[3 * r + f] += (1.0 / 6.0) * g6[r][f];
+        acc[9 + r] += (1.0 / 6.0) * g6[r][3];
+        acc[12 + r] += (1.0 / 6.0) * g6[r][4];
+        acc[15 + r] += (1.0 / 6.0) * g6[r][5];
+      }
+    }
+  double* o = out + 18 * (((long)k * b.nj + j) * b.ni + i);
+  for (int n = 0; n < 18; ++n) o[n] = acc[n];
 }
 
 // procBlock::UpdateAuxillaryVariables (procBlock.cpp:6171): temperature_ and

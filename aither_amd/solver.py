@@ -146,7 +146,9 @@ class Solver:
         n_eq = self.cfg.n_eq
         ghost = field in ("state", "update", "temperature", "viscosity")
         comps = n_eq if field in ("state", "residual", "cons_n", "update",
-                                  "cons_nm1") else 1
+                                  "cons_nm1") else \
+            9 if field == "vel_grad" else \
+            3 if field in ("temp_grad", "dens_grad", "press_grad") else 1
         pad = 2 * ng if ghost else 0
         return (g.nk + pad, g.nj + pad, g.ni + pad, comps)
 

@@ -67,7 +67,14 @@ enum { AGX_FIELD_STATE = 0,      /* state_      nEq, with ghosts           */
        AGX_FIELD_DIAGONAL = 6,   /* linearSolver a_ (scalar) 1, no ghosts  */
        AGX_FIELD_TEMPERATURE = 7,/* temperature_ 1,  with ghosts           */
        AGX_FIELD_VISCOSITY = 8,  /* viscosity_  1,   with ghosts           */
-       AGX_FIELD_CONS_NM1 = 9    /* consVarsNm1_ nEq, no ghosts            */
+       AGX_FIELD_CONS_NM1 = 9,   /* consVarsNm1_ nEq, no ghosts            */
+       /* cell-centre gradients (velocityGrad_, temperatureGrad_, densityGrad_,
+        * pressureGrad_; procBlock.cpp:1397-1449, :5950-5954): the mean of the six
+        * Green-Gauss face gradients of the cell, formed ON DEMAND from the state
+        * the device holds (they are not kept between iterations); no ghosts.
+        * VEL_GRAD: 9 per cell, [3 r + c] = d(velocity c)/d(x_r) (tensor.hpp) */
+       AGX_FIELD_VEL_GRAD = 10, AGX_FIELD_TEMP_GRAD = 11,
+       AGX_FIELD_DENS_GRAD = 12, AGX_FIELD_PRESS_GRAD = 13
 };
 
 /* what a halo exchange carries (gridLevel.cpp:299-313, utility.cpp:400-423) */

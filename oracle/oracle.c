@@ -1107,6 +1107,85 @@ static void calc_grads(const blk_t *b, int d, int i, int j, int k,
   }
 }
 
+/* Cell-centre gradients as the reference accumulates them: one sixth of each of
+ * the six face gradients of the cell (procBlock.cpp:1397-1449 in the viscous flux
+ * routines, CalcGradsI/J/K :5950-5954 otherwise); six fields: u, v, w, T, rho, p.
+ * Formed on demand from the current state.  out: [cell][18] = velGrad[9] (3 r + c),
+ * tGrad[3], rhoGrad[3], pGrad[3]; physical cells, i fastest. */
+static double grad_field(const ora_ctx *c, const blk_t *b, long cell, int f) {
+  const double *s = b->state + NEQ * cell;
+  if (f < 3) return s[1 + f];
+  if (f == 3) return temperature(c, s);
+  return f == 4 ? s[0] : s[4];
+}
+static void face_grad6(const ora_ctx *c, const blk_t *b, int d, int i, int j, int k,
+                       double g6[3][6]) {
+  static const int o[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  const int *od = o[d];
+  double au[3][3], al[3][3];
+  {
+    double a0[3], a1[3], a2[3];
+    area_vec(b->fa[d] + 4 * FI(b, d, i, j, k), a0);
+    area_vec(b->fa[d] + 4 * FI(b, d, i + od[0], j + od[1], k + od[2]), a1);
+    area_vec(b->fa[d] + 4 * FI(b, d, i - od[0], j - od[1], k - od[2]), a2);
+    for (int q = 0; q < 3; ++q) { au[d][q] = 0.5 * (a0[q] + a1[q]); al[d][q] = 0.5 * (a0[q] + a2[q]); }
+  }
+  for (int t = 0; t < 3; ++t) {
+    if (t == d) continue;
+    const int *ot = o[t];
+    double a0[3], a1[3];
+    area_vec(b->fa[t] + 4 * FI(b, t, i + ot[0], j + ot[1], k + ot[2]), a0);
+    area_vec(b->fa[t] + 4 * FI(b, t, i + ot[0] - od[0], j + ot[1] - od[1], k + ot[2] - od[2]), a1);
+    for (int q = 0; q < 3; ++q) au[t][q] = 0.5 * (a0[q] + a1[q]);
+    area_vec(b->fa[t] + 4 * FI(b, t, i, j, k), a0);
+    area_vec(b->fa[t] + 4 * FI(b, t, i - od[0], j - od[1], k - od[2]), a1);
+    for (int q = 0; q < 3; ++q) al[t][q] = 0.5 * (a0[q] + a1[q]);
+  }
+  const long cL = CI(b, i - od[0], j - od[1], k - od[2]);
+  const long cU = CI(b, i, j, k);
+  const double invVol = 1.0 / (0.5 * (b->vol[cL] + b->vol[cU]));
+  for (int f = 0; f < 6; ++f) {
+    double vl[3], vu[3];
+    const double fL = grad_field(c, b, cL, f), fU = grad_field(c, b, cU, f);
+    vl[d] = fL;
+    vu[d] = fU;
+    for (int t = 0; t < 3; ++t) {
+      if (t == d) continue;
+      const int *ot = o[t];
+      const long cUu = CI(b, i + ot[0], j + ot[1], k + ot[2]);
+      const long cLu = CI(b, i + ot[0] - od[0], j + ot[1] - od[1], k + ot[2] - od[2]);
+      const long cUl = CI(b, i - ot[0], j - ot[1], k - ot[2]);
+      const long cLl = CI(b, i - ot[0] - od[0], j - ot[1] - od[1], k - ot[2] - od[2]);
+      vu[t] = 0.25 * (fL + fU + grad_field(c, b, cUu, f) + grad_field(c, b, cLu, f));
+      vl[t] = 0.25 * (fL + fU + grad_field(c, b, cUl, f) + grad_field(c, b, cLl, f));
+    }
+    for (int r = 0; r < 3; ++r)
+      g6[r][f] = (vu[0] * au[0][r] - vl[0] * al[0][r] + vu[1] * au[1][r] - vl[1] * al[1][r] +
+                  vu[2] * au[2][r] - vl[2] * al[2][r]) * invVol;
+  }
+}
+static void cell_gradients(const ora_ctx *c, const blk_t *b, double *out) {
+  const double sixth = 1.0 / 6.0;
+  for (int k = 0; k < b->nk; ++k)
+    for (int j = 0; j < b->nj; ++j)
+      for (int i = 0; i < b->ni; ++i) {
+        double acc[18];
+        for (int q = 0; q < 18; ++q) acc[q] = 0.0;
+        for (int d = 0; d < 3; ++d)
+          for (int up = 0; up < 2; ++up) {
+            double g6[3][6];
+            face_grad6(c, b, d, i + (up && d == 0), j + (up && d == 1), k + (up && d == 2), g6);
+            for (int r = 0; r < 3; ++r) {
+              for (int f = 0; f < 3; ++f) acc[3 * r + f] += sixth * g6[r][f];
+              acc[9 + r] += sixth * g6[r][3];
+              acc[12 + r] += sixth * g6[r][4];
+              acc[15 + r] += sixth * g6[r][5];
+            }
+          }
+        memcpy(out + 18 * PI(b, i, j, k), acc, sizeof acc);
+      }
+}
+
 /* FaceReconCentral reconstruction.hpp:315-328 with LagrangeCoeff(.,1,0,0) */
 static void central_coeffs(double wU, double wD, double *cf) {
   const double w[2] = {wU, wD};
@@ -1298,11 +1377,21 @@ static void rhs_b(const ora_ctx *c, const blk_t *b, int i, int j, int k,
 
 /* RusanovScalarOffDiagonal fluxJacobian.cpp:122-162, FaceSpectralRadius
  * spectralRadius.hpp:182-203, ConvectiveFluxUpdate inviscidFlux.hpp:544-562 */
-static void off_diagonal(const ora_ctx *c, const double *state,
+static void off_diagonal(const ora_ctx *c, const double *state, const double *diag,
                          const double *update, const double *fArea, double mu,
                          double dist, int positive, double *out) {
   double su[NEQ], fo[NEQ], fn[NEQ];
   update_prim_with_cons(c, state, update, su);
+  if (c->cfg.inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE) {
+    /* RoeOffDiagonal fluxJacobian.cpp:240-291 (inviscid: the viscous branch of the
+     * reference receives dist and f1 in swapped order, :232-234 vs :240-245, and
+     * divides by f1 = 0 in laminar runs; it is not restated) */
+    roe_flux(c, state, diag, fArea, fo);
+    if (positive) roe_flux(c, su, diag, fArea, fn);
+    else roe_flux(c, diag, su, fArea, fn);
+    for (int e = 0; e < NEQ; ++e) out[e] = fArea[3] * (fn[e] - fo[e]);
+    return;
+  }
   phys_flux(c, state, fArea, fo);
   phys_flux(c, su, fArea, fn);
   double sr = 0.5 * fArea[3] * (fabs(dot3(state + 1, fArea)) + sos(c, state));
@@ -1336,7 +1425,7 @@ static void implicit_lower(const ora_ctx *c, const blk_t *b, int i, int j,
       const double dist = proj_c2c(b, d, i, j, k);
       const long q = CI(b, ii, jj, kk);
       double od[NEQ];
-      off_diagonal(c, b->state + NEQ * q, x + NEQ * q,
+      off_diagonal(c, b->state + NEQ * q, b->state + NEQ * CI(b, i, j, k), x + NEQ * q,
                    b->fa[d] + 4 * FI(b, d, i, j, k),
                    c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 1, od);
       for (int e = 0; e < NEQ; ++e) L[e] += od[e];
@@ -1354,7 +1443,7 @@ static void implicit_upper(const ora_ctx *c, const blk_t *b, int i, int j,
       const double dist = proj_c2c(b, d, ii, jj, kk);
       const long q = CI(b, ii, jj, kk);
       double od[NEQ];
-      off_diagonal(c, b->state + NEQ * q, x + NEQ * q,
+      off_diagonal(c, b->state + NEQ * q, b->state + NEQ * CI(b, i, j, k), x + NEQ * q,
                    b->fa[d] + 4 * FI(b, d, ii, jj, kk),
                    c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 0, od);
       for (int e = 0; e < NEQ; ++e) U[e] += od[e];
@@ -1664,6 +1753,16 @@ static double *field_ptr(blk_t *b, int field, long *n) {
 }
 int ora_field_download(ora_ctx *c, int id, int field, double *out) {
   if (id < 0 || id >= c->nblk) return fail("bad block id");
+  if (field >= AGX_FIELD_VEL_GRAD && field <= AGX_FIELD_PRESS_GRAD) {
+    blk_t *b = &c->blk[id];
+    double *all = (double *)malloc(sizeof(double) * 18 * b->ncell);
+    cell_gradients(c, b, all);
+    const int off = field == AGX_FIELD_VEL_GRAD ? 0 : 9 + 3 * (field - AGX_FIELD_TEMP_GRAD);
+    const int nc = field == AGX_FIELD_VEL_GRAD ? 9 : 3;
+    for (long q = 0; q < b->ncell; ++q) memcpy(out + nc * q, all + 18 * q + off, sizeof(double) * nc);
+    free(all);
+    return 0;
+  }
   long n;
   double *p = field_ptr(&c->blk[id], field, &n);
   if (!p) return fail("unknown field %d", field);

@@ -247,6 +247,13 @@ CASES = {
     "visc_heatflux_wall_lusgs": dict(
         n=(10, 9, 8), stretch=1.15, bcs=WALL_HEATFLUX, equation_set="navierStokes",
         time_integration="implicitEuler", matrix_solver="lusgs", cfl=10.0),
+    # inviscidFluxJacobian: approximateRoe (RoeOffDiagonal fluxJacobian.cpp:240-291)
+    "roe_jacobian_lusgs2": dict(
+        n=(11, 10, 9), stretch=1.15, bcs=FARFIELD, inv_flux_jac="approximateRoe",
+        time_integration="implicitEuler", matrix_solver="lusgs", matrix_sweeps=2, cfl=10.0),
+    "roe_jacobian_dplur": dict(
+        n=(10, 9, 8), stretch=1.1, inviscid_flux="ausm", inv_flux_jac="approximateRoe",
+        time_integration="implicitEuler", matrix_solver="dplur", matrix_sweeps=3, cfl=5.0),
     # viscousFaceReconstruction: centralFourth (FaceReconCentral4th
     # reconstruction.hpp:335-379): four-cell face state and viscosity
     "visc_central4th_lusgs": dict(
@@ -407,6 +414,10 @@ def test_temperature_viscosity_fields(agx, oracle):
         assert rel_err(a[inner], b[inner]) < RTOL, f
         # ghost layers except the block's corner lines, which nobody assigns
         assert rel_err(a[g:-g, g:-g, :], b[g:-g, g:-g, :]) < RTOL, f
+    # cell-centre gradients (velocityGrad_ ... pressureGrad_), on demand from that state
+    for f in ("vel_grad", "temp_grad", "dens_grad", "press_grad"):
+        a, b = sg.download(f, 0), so2.download(f, 0)
+        assert np.abs(b).max() > 0 and rel_err(a, b) < RTOL, f
     _close(sg, so, so2)
 
 
