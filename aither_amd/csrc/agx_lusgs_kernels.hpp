@@ -459,10 +459,16 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
         if (pst[m] != ~0u) {
 #pragma unroll
           for (int h = 0; h < 3; ++h) {
-            double* p = reinterpret_cast<double*>(
-                const_cast<char*>(z.pab(PA_X + h)) + kbase * 16 + pst[m]);
-            __hip_atomic_store(p, xst[m][h].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p + 1, xst[m][h].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // one 16-byte write-through (sc1) store per pair: what an agent-scope
+            // atomic store lowers to, at twice the width HIP's atomics offer
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const char* base = z.pab(PA_X + h) + kbase * 16;
+            const v2d val = {xst[m][h].x, xst[m][h].y};
+            // (s_nop 4: the base may have been written by a v_readlane just before --
+            // VALU-writes-SGPR -> VMEM needs 5 wait states, and the compiler's hazard
+            // recogniser does not look inside inline asm)
+            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1"
+                         :: "v"(pst[m]), "v"(val), "s"(base) : "memory");
           }
         }
         pst[m] = ~0u;

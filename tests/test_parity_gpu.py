@@ -124,6 +124,23 @@ def test_kernel_variants_agree(agx):
 
 
 @pytest.mark.gpu
+def test_viscous_kernel_forms_agree(agx):
+    """The LDS-staged viscous kernel (default), the face-once form without staging
+    (the fallback of blocks too large for 32-bit plane offsets) and the
+    one-thread-per-cell form are three statements of the same viscous residual;
+    ragged tile edges in i and j (62 x 6 owned cells per workgroup)."""
+    wall = {3: ("viscousWall", 2), 1: ("characteristic", 1),
+            2: ("characteristic", 1), 4: ("characteristic", 1)}
+    case = synthetic.single_block_case(n=(70, 15, 9), stretch=1.1, skew=0.01, bcs=wall,
+                                       equation_set="navierStokes",
+                                       time_integration="rk4", cfl=0.3)
+    ref = _run_with_env(agx, case, 2, {"AGX_VISC": "tile"})
+    for kind in ("march", "gather"):
+        got = _run_with_env(agx, case, 2, {"AGX_VISC": kind})
+        assert rel_err(got, ref) < 1e-12, kind
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sweeps", [1, 2])
 def test_lusgs_sweep_forms_agree(agx, sweeps):
     """The pipelined k-plane sweep on the diagonal-ordered arrays (default) and
