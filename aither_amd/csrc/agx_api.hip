@@ -1257,7 +1257,10 @@ int agx_phase_implicit_begin(agx_ctx* c) {
     if (b.d2.base) {
       // diagonal terms, b and x0 straight into the D2 arrays of the sweeps
       const dim3 grid((b.d2.Pi + TT - 1) / TT, (b.d2.Pj + TT - 1) / TT, b.nk + 2 * b.ng);
-      hipLaunchKernelGGL(k_lusgs_prepare, grid, dim3(256), 0, c->stream, b, c->gas, c->sp);
+      bool conn = false;
+      for (int q = 0; q < 6; ++q) conn = conn || b.side_conn[q] != 0;
+      hipLaunchKernelGGL(k_lusgs_prepare, grid, dim3(256), 0, c->stream, b, c->gas, c->sp,
+                         (c->sp.requires_init || conn) ? 1 : 0);
       continue;
     }
     if (!c->sp.requires_init)   // x_[bb].Zero() incl. ghosts, linearSolver.cpp:141

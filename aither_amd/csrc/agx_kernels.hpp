@@ -648,17 +648,24 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
       double ak_up[4];
       b.areab(2, qb + skb, ak_up);
       double nxt[AGX_NEQ], nwk, nwi, nwj;
-      if AGX_AB(128) {
+      auto prefetch = [&]() {
+        if AGX_AB(128) {
 #pragma unroll
-        for (int e = 0; e < AGX_NEQ; ++e) nxt[e] = W[2 * H - 1][e];
-        nwk = wk[0]; nwi = wk[0]; nwj = wk[0];
-      } else {
+          for (int e = 0; e < AGX_NEQ; ++e) nxt[e] = W[2 * H - 1][e];
+          nwk = wk[0]; nwi = wk[0]; nwj = wk[0];
+        } else {
 #pragma unroll
-        for (int e = 0; e < AGX_NEQ; ++e) nxt[e] = b.ldb(b.st + e, qb + (H + 1) * skb);
-        nwk = b.ldb(PL_WID + 2, qb + (H + 1) * skb);
-        nwi = b.ldb(PL_WID + 0, qb + skb);
-        nwj = b.ldb(PL_WID + 1, qb + skb);
-      }
+          for (int e = 0; e < AGX_NEQ; ++e) nxt[e] = b.ldb(b.st + e, qb + (H + 1) * skb);
+          nwk = b.ldb(PL_WID + 2, qb + (H + 1) * skb);
+          nwi = b.ldb(PL_WID + 0, qb + skb);
+          nwj = b.ldb(PL_WID + 1, qb + skb);
+        }
+      };
+      // MUSCL and below: requested first, a whole step ahead of its use.  WENO: the
+      // k- and i-face with their coefficient sets leave no room for eight more live
+      // values (256 VGPRs + scratch), so there it is requested after the i-face.
+      constexpr bool LATE = H >= 3;
+      if (!LATE) prefetch();
       // InvCellSpectralRadius spectralRadius.hpp:44-64, one direction per block
       const double* sc = W[H - 1];
       const double cs = sound_speed(g, sc);
@@ -745,6 +752,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (LATE) prefetch();
       // ---- j face (lower): handed to the row below through LDS.  Rows 0 and 1
       // leave this flux to the two halo waves (BAL): the cell waves of those rows
       // share a SIMD with another cell wave, the halo waves with one only, and
