@@ -84,6 +84,11 @@ def make_deck(**kw):
         State("viscousWall", dict(tag=4, temperature=300.0,
                                   velocity=[5.0, 0.0, 0.0])),
         State("viscousWall", dict(tag=5, heatFlux=2.0e3)),
+        State("inlet", dict(tag=6, pressure=101325.0, density=1.225,
+                            velocity=[50.0, 20.0, 10.0], nonreflecting=True,
+                            lengthScale=1.0)),
+        State("pressureOutlet", dict(tag=7, pressure=101325.0, nonreflecting=True,
+                                     lengthScale=1.0)),
     ]
     return d
 

@@ -53,6 +53,10 @@ struct Block {
   bool state_is_a = true;
   agx_bc_surface* surf_dev = nullptr;
   std::vector<agx_bc_surface> surf_host;
+  // nonreflecting inlet / outlet surfaces: offsets | gradients | Mach (BlockDev)
+  int* nr_off_dev = nullptr;
+  double* nr_mem = nullptr;
+  long nr_max = 0;            // cells of the largest such surface (0: none)
 };
 
 struct ConnSide {          // what side s receives / sends
@@ -118,6 +122,7 @@ struct agx_ctx {
   int spin_limit = 4000000;  // AGX_SPIN_LIMIT: polls before a waiting plane gives up
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
+  bool have_time_n = false;  // agx_store_time_n has run (nonreflecting BCs read consVarsN)
   // agx_iterate fills the ghost cells for the NEXT call right after the update,
   // behind the norm read-back the host waits for, so that the GPU does not idle
   // while the host turns the iteration around
@@ -341,8 +346,7 @@ int check_device_error(agx_ctx* c) {
     if (code == 2)
       return fail("LU-SGS pipeline: a k-plane waited beyond the spin limit for its "
                   "predecessor (AGX_LUSGS=plane selects the launch-per-hyperplane form)");
-    return fail("a boundary-condition variant outside this build's coverage "
-                "was requested (nonreflecting inlet/outlet)");
+    return fail("a boundary-condition variant outside this build's coverage was requested");
   }
   return 0;
 }
@@ -448,6 +452,8 @@ void launch_inv(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
 }
 
 bool can_fuse(const agx_ctx* c) {
+  // (nonreflecting surfaces read the gradients of the residual's own state after it)
+  for (const auto& blk : c->blocks) if (blk.nr_max > 0) return false;
   return c->allow_fuse && !c->use_gather && !c->sp.implicit && !c->sp.viscous;
 }
 
@@ -593,6 +599,11 @@ int bc_pass(agx_ctx* c, bool faces, int viscous) {
         const int d3 = (st - 1) / 2, d1 = (d3 + 1) % 3, d2 = (d3 + 2) % 3;
         const int lo[3] = {s.imin, s.jmin, s.kmin}, hi[3] = {s.imax, s.jmax, s.kmax};
         nmax = std::max(nmax, (long)(hi[d1] - lo[d1]) * (hi[d2] - lo[d2]));
+      }
+      if (!viscous && blk.nr_max > 0) {
+        if (!c->have_time_n)
+          return fail("nonreflecting boundary: the state at time n has not been stored");
+        hipLaunchKernelGGL(k_nr_mach, dim3(b.nsurf), dim3(256), 0, c->stream, b, c->gas);
       }
       if (nmax > 0)
         hipLaunchKernelGGL(k_bc_faces, dim3((nmax + 255) / 256, b.nsurf), dim3(256), 0,
@@ -753,6 +764,8 @@ void agx_ctx_destroy(agx_ctx* c) {
     if (b.d2_tab) hipFree(b.d2_tab);
     if (b.kp_mem) hipFree(b.kp_mem);
     if (b.surf_dev) hipFree(b.surf_dev);
+    if (b.nr_off_dev) hipFree(b.nr_off_dev);
+    if (b.nr_mem) hipFree(b.nr_mem);
   }
   for (auto& k : c->conns) {
     for (int s = 0; s < 2; ++s) {
@@ -949,6 +962,35 @@ int agx_block_set_bcs(agx_ctx* c, int id, int n, const agx_bc_surface* s) {
   }
   for (int q = 0; q < 6; ++q)
     b.d.side_conn[q] = n_conn[q] == 0 ? 0 : (n_other[q] == 0 ? 1 : 2);
+  // nonreflecting inlet / outlet surfaces keep the gradients of their adjacent cells
+  // and their Mach mean / maximum between a residual and the next ghost fills
+  if (b.nr_off_dev) HIPCHK(hipFree(b.nr_off_dev));
+  if (b.nr_mem) HIPCHK(hipFree(b.nr_mem));
+  b.nr_off_dev = nullptr; b.nr_mem = nullptr; b.nr_max = 0;
+  b.d.nr_off = nullptr; b.d.nr_grad = nullptr; b.d.nr_mach = nullptr;
+  std::vector<int> off(n > 0 ? n : 1, -1);
+  long total = 0;
+  for (int q = 0; q < n; ++q) {
+    const int t = s[q].bc_type;
+    if (!s[q].state.is_nonreflecting || (t != AGX_BC_INLET && t != AGX_BC_PRESSURE_OUTLET)) continue;
+    const int st = surface_type(s[q]);
+    const int d3 = (st - 1) / 2, d1 = (d3 + 1) % 3, d2 = (d3 + 2) % 3;
+    const int lo[3] = {s[q].imin, s[q].jmin, s[q].kmin}, hi[3] = {s[q].imax, s[q].jmax, s[q].kmax};
+    const long cells = (long)(hi[d1] - lo[d1]) * (hi[d2] - lo[d2]);
+    off[q] = (int)total;
+    total += cells;
+    b.nr_max = std::max(b.nr_max, cells);
+  }
+  if (total > 0) {
+    HIPCHK(hipMalloc((void**)&b.nr_off_dev, sizeof(int) * n));
+    HIPCHK(hipMemcpy(b.nr_off_dev, off.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    const size_t nd = (size_t)12 * total + 2 * (size_t)n;
+    HIPCHK(hipMalloc((void**)&b.nr_mem, sizeof(double) * nd));
+    HIPCHK(hipMemset(b.nr_mem, 0, sizeof(double) * nd));   // gradients before the first residual
+    b.d.nr_off = b.nr_off_dev;
+    b.d.nr_grad = b.nr_mem;
+    b.d.nr_mach = b.nr_mem + 12 * total;
+  }
   return 0;
 }
 
@@ -1162,6 +1204,7 @@ int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
 
 int agx_store_time_n(agx_ctx* c, int also_nm1) {
   if (flush_consn(c)) return 1;
+  c->have_time_n = true;
   // Explicit fused path: the stage-0 launch of k_residual_tile forms
   // cons(state) anyway and writes it to consVarsN itself (5 stores instead of a
   // separate 5-load/5-store pass); anything else that touches consVarsN or the
@@ -1242,6 +1285,15 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
       }
     HIPCHK(hipGetLastError());
   }
+  // the gradients of this residual's state feed the nonreflecting ghost states of
+  // the ghost fills up to the next residual (CalcGrads*, procBlock.cpp:6143)
+  for (auto& blk : c->blocks)
+    if (blk.nr_max > 0) {
+      Timer t(c, G_BC);
+      hipLaunchKernelGGL(k_nr_grads, dim3((blk.nr_max + 255) / 256, blk.d.nsurf), dim3(256), 0,
+                         c->stream, blk.d, c->gas);
+      HIPCHK(hipGetLastError());
+    }
   return 0;
 }
 

@@ -471,11 +471,18 @@ __device__ __forceinline__ void extrap_hold(const double* bnd, double factor,
   for (int e = 0; e < AGX_NEQ; ++e) out[e] = t[e];
 }
 
+// what the nonreflecting (LODI) branches of GetGhostState read besides the interior
+// state: dt and the state at time n of the adjacent cell, its pressure / velocity
+// gradients of the last residual, Mach mean / maximum over the surface
+// (procBlock.cpp:2497-2512, :6233-6262)
+struct NrDev { double dt, sn[AGX_NEQ], pg[3], vg[9], avg_mach, max_mach; };
+
 // GetGhostState; returns false for a BC variant this build does not cover
 __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
                                    const double* area_unit, int surf,
                                    const agx_bc_state& d, int layer,
-                                   double wall_dist, double* gh) {
+                                   double wall_dist, double* gh,
+                                   const NrDev* nr = nullptr) {
 #pragma unroll
   for (int e = 0; e < AGX_NEQ; ++e) gh[e] = in[e];
   const double sgn = (surf % 2 == 1) ? -1.0 : 1.0;
@@ -502,7 +509,7 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
     }
     case AGX_BC_CHARACTERISTIC:
     case AGX_BC_INLET: {
-      if (bc == AGX_BC_INLET && d.is_nonreflecting) return false;
+      if (bc == AGX_BC_INLET && d.is_nonreflecting && !nr) return false;
       const double fs[AGX_NEQ] = {d.density, d.velocity[0], d.velocity[1],
                                   d.velocity[2], d.pressure};
       const double vn = dot3(in + 1, n);
@@ -519,9 +526,22 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
         const double rc = in[0] * c;
         const double vd[3] = {fs[1] - in[1], fs[2] - in[2], fs[3] - in[3]};
         gh[4] = 0.5 * (fs[4] + in[4] - rc * dot3(n, vd));
-        const double dp = fs[4] - gh[4];
-        gh[0] = fs[0] - dp / (c * c);
-        for (int q = 0; q < 3; ++q) gh[1 + q] = fs[1 + q] - n[q] * dp / rc;
+        if (bc == AGX_BC_INLET && d.is_nonreflecting) {
+          // LODI terms, ghostStates.cpp:435-462
+          const double sigma = 0.25;
+          const double rhoN = nr->sn[0], sosN = sound_speed(g, nr->sn), rcN = rhoN * sosN;
+          const double dpn = gh[4] - nr->sn[4];
+          const double alpha = sigma * sosN / d.length_scale;
+          gh[0] = (rhoN + nr->dt * alpha * fs[0] + dpn / (sosN * sosN)) / (1.0 + nr->dt * alpha);
+          const double kk = alpha * (1.0 - nr->max_mach * nr->max_mach);
+          for (int q = 0; q < 3; ++q)
+            gh[1 + q] = (nr->sn[1 + q] + nr->dt * kk * fs[1 + q] - n[q] * dpn / rcN) /
+                        (1.0 + nr->dt * kk);
+        } else {
+          const double dp = fs[4] - gh[4];
+          gh[0] = fs[0] - dp / (c * c);
+          for (int q = 0; q < 3; ++q) gh[1 + q] = fs[1 + q] - n[q] * dp / rc;
+        }
       } else {
         const double rc = in[0] * c;
         const double dp = in[4] - fs[4];
@@ -578,10 +598,34 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
       return true;
     }
     case AGX_BC_PRESSURE_OUTLET: {
-      if (d.is_nonreflecting) return false;
+      if (d.is_nonreflecting && !nr) return false;
       const double c = sound_speed(g, in);
       const double rc = in[0] * c;
       gh[4] = d.pressure;
+      if (d.is_nonreflecting) {
+        // LODI + transverse terms, ghostStates.cpp:614-643
+        const double* sn = nr->sn;
+        const double dv[3] = {in[1] - sn[1], in[2] - sn[2], in[3] - sn[3]};
+        const double sigma = 0.25;
+        const double rhoN = sn[0], sosN = sound_speed(g, sn), rcN = rhoN * sosN;
+        const double kk = sigma * sosN * (1.0 - nr->max_mach * nr->max_mach) / d.length_scale;
+        const double pgn = dot3(nr->pg, n), vnn = dot3(sn + 1, n);
+        double tv[3], velT[3], vgt[9], dvn[3] = {0.0, 0.0, 0.0}, sum = 0.0;
+        for (int r = 0; r < 3; ++r) {            // tensor::RemoveComponent (rows)
+          const double rn = dot3(nr->vg + 3 * r, n);
+          for (int q = 0; q < 3; ++q) { vgt[3 * r + q] = nr->vg[3 * r + q] - rn * n[q]; sum += vgt[3 * r + q]; }
+        }
+        for (int r = 0; r < 3; ++r)              // tensor::LinearCombination
+          for (int q = 0; q < 3; ++q) dvn[q] += vgt[3 * r + q] * n[r];
+        for (int q = 0; q < 3; ++q) {
+          velT[q] = sn[1 + q] - vnn * n[q];
+          tv[q] = (nr->pg[q] - pgn * n[q]) - rcN * dvn[q];
+        }
+        const double dvt = sum - (dvn[0] + dvn[1] + dvn[2]);
+        const double trans = -0.5 * (dot3(velT, tv) + g.gamma * sn[4] * dvt);
+        gh[4] = (sn[4] + rcN * dot3(dv, n) + nr->dt * kk * d.pressure -
+                 nr->dt * nr->avg_mach * trans) / (1.0 + nr->dt * kk);
+      }
       const double dp = in[4] - gh[4];
       gh[0] = in[0] - dp / (c * c);
       for (int q = 0; q < 3; ++q) gh[1 + q] = in[1 + q] + n[q] * dp / rc;

@@ -40,6 +40,13 @@ struct BlockDev {
   D2Dev d2;                   // diagonal-ordered arrays of the LU-SGS path (agx_lusgs.hpp)
   const agx_bc_surface* surf; // boundaryConditions      boundaryConditions.hpp:231
   int nsurf, nsurf_i, nsurf_j, nsurf_k;
+  // nonreflecting inlet / outlet surfaces (null when the block has none): per
+  // surface the offset of its cells in nr_grad (-1: not such a surface),
+  // {pGrad[3], velGrad[9]} of the adjacent cell from the last residual, and the
+  // surface's Mach {mean, max}
+  const int* nr_off;
+  double* nr_grad;
+  double* nr_mach;
   // per side (surface type 1..6): 0 no connection BC on it, 1 all of it is
   // interblock / periodic, 2 mixed (look the cell up in `surf`)
   int side_conn[6];
@@ -1360,8 +1367,69 @@ __global__ void k_bc_faces(BlockDev b, GasDev g, int viscous, int* err) {
     c[d3] = gCell; const long qg = b.idx(c[0], c[1], c[2]);
     double in[AGX_NEQ], gh[AGX_NEQ];
     load5(b.state, qs, in);
-    if (!ghost_state(g, in, bc, area, st, sf.state, layer, wd, gh)) { *err = 1; return; }
+    NrDev nr;
+    const bool is_nr = !viscous && sf.state.is_nonreflecting && b.nr_off && b.nr_off[sn] >= 0 &&
+                       (bc == AGX_BC_INLET || bc == AGX_BC_PRESSURE_OUTLET);
+    if (is_nr) {
+      c[d3] = st % 2 == 0 ? r3 - 1 : r3;                  // the adjacent cell
+      const long qa = b.idx(c[0], c[1], c[2]);
+      nr.dt = b.dt[qa];
+      double un[AGX_NEQ];
+      load5(b.consn, qa, un);
+      cons_to_prim(g, un, nr.sn);
+      const double* gr = b.nr_grad + 12 * ((long)b.nr_off[sn] + rem);
+      for (int q = 0; q < 3; ++q) nr.pg[q] = gr[q];
+      for (int q = 0; q < 9; ++q) nr.vg[q] = gr[3 + q];
+      nr.avg_mach = b.nr_mach[2 * sn];
+      nr.max_mach = b.nr_mach[2 * sn + 1];
+    }
+    if (!ghost_state(g, in, bc, area, st, sf.state, layer, wd, gh, is_nr ? &nr : nullptr)) {
+      *err = 1;
+      return;
+    }
     store5(b.state, qg, gh);
+  }
+}
+
+// Nonreflecting surfaces, before a ghost fill: Mach mean / maximum of the adjacent
+// cells (GetGhostStates procBlock.cpp:6233-6262); one workgroup per surface
+__global__ void __launch_bounds__(256) k_nr_mach(BlockDev b, GasDev g) {
+  __shared__ double ssum[256], smax[256];
+  const int sn = blockIdx.x;
+  if (b.nr_off[sn] < 0) return;
+  const agx_bc_surface sf = b.surf[sn];
+  const int st = surface_type(sf);
+  const int d3 = (st - 1) / 2, d1 = (d3 + 1) % 3, d2 = (d3 + 2) % 3;
+  const int lo[3] = {sf.imin, sf.jmin, sf.kmin}, hi[3] = {sf.imax, sf.jmax, sf.kmax};
+  const int n1 = hi[d1] - lo[d1], n2 = hi[d2] - lo[d2];
+  double sum = 0.0, mx = -1.7976931348623157e308;
+  for (int t = threadIdx.x; t < n1 * n2; t += 256) {
+    int c[3];
+    if (d1 < d2) { c[d1] = lo[d1] + t % n1; c[d2] = lo[d2] + t / n1; }
+    else { c[d2] = lo[d2] + t % n2; c[d1] = lo[d1] + t / n2; }
+    c[d3] = lo[d3];
+    double area[4], s[AGX_NEQ];
+    load_area(b, d3, b.idx(c[0], c[1], c[2]), area);
+    c[d3] = st % 2 == 0 ? lo[d3] - 1 : lo[d3];
+    load5(b.state, b.idx(c[0], c[1], c[2]), s);
+    const double sg = st % 2 == 1 ? -1.0 : 1.0;
+    const double mach = sg * dot3(s + 1, area) / sound_speed(g, s);
+    sum += mach;
+    mx = fmax(mx, mach);
+  }
+  ssum[threadIdx.x] = sum;
+  smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      ssum[threadIdx.x] += ssum[threadIdx.x + off];
+      smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    b.nr_mach[2 * sn] = ssum[0] / (double)(n1 * n2);
+    b.nr_mach[2 * sn + 1] = smax[0];
   }
 }
 
@@ -1854,13 +1922,7 @@ __device__ inline void face_grad6(const BlockDev& b, const GasDev& g, int d, lon
                   vu[2] * au[2][r] - vl[2] * al[2][r]) * inv_vol;
   }
 }
-__global__ void __launch_bounds__(256) k_cell_grads(BlockDev b, GasDev g, double* out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= b.ni || j >= b.nj) return;
-  const long q = b.idx(i, j, k);
-  double acc[18];
+__device__ inline void cell_grads18(const BlockDev& b, const GasDev& g, long q, double* acc) {
   for (int n = 0; n < 18; ++n) acc[n] = 0.0;
   for (int d = 0; d < 3; ++d)
     for (int up = 0; up < 2; ++up) {
@@ -1873,8 +1935,42 @@ __global__ void __launch_bounds__(256) k_cell_grads(BlockDev b, GasDev g, double
         acc[15 + r] += (1.0 / 6.0) * g6[r][5];
       }
     }
+}
+__global__ void __launch_bounds__(256) k_cell_grads(BlockDev b, GasDev g, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  double acc[18];
+  cell_grads18(b, g, b.idx(i, j, k), acc);
   double* o = out + 18 * (((long)k * b.nj + j) * b.ni + i);
   for (int n = 0; n < 18; ++n) o[n] = acc[n];
+}
+
+// Nonreflecting surfaces, after a residual: pressure and velocity gradient of the
+// cells next to the surface (the slice AssignInviscidGhostCells takes of
+// pressureGrad_ / velocityGrad_, procBlock.cpp:2514-2515), kept for the ghost fills
+// up to the next residual.  blockIdx.y is the surface.
+__global__ void __launch_bounds__(256) k_nr_grads(BlockDev b, GasDev g) {
+  const int sn = blockIdx.y;
+  if (b.nr_off[sn] < 0) return;
+  const agx_bc_surface sf = b.surf[sn];
+  const int st = surface_type(sf);
+  const int d3 = (st - 1) / 2, d1 = (d3 + 1) % 3, d2 = (d3 + 2) % 3;
+  const int lo[3] = {sf.imin, sf.jmin, sf.kmin}, hi[3] = {sf.imax, sf.jmax, sf.kmax};
+  const int n1 = hi[d1] - lo[d1], n2 = hi[d2] - lo[d2];
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n1 * n2) return;
+  const int rem = (int)t;
+  int c[3];
+  if (d1 < d2) { c[d1] = lo[d1] + rem % n1; c[d2] = lo[d2] + rem / n1; }
+  else { c[d2] = lo[d2] + rem % n2; c[d1] = lo[d1] + rem / n2; }
+  c[d3] = st % 2 == 0 ? lo[d3] - 1 : lo[d3];
+  double acc[18];
+  cell_grads18(b, g, b.idx(c[0], c[1], c[2]), acc);
+  double* o = b.nr_grad + 12 * ((long)b.nr_off[sn] + rem);
+  for (int q = 0; q < 3; ++q) o[q] = acc[15 + q];
+  for (int q = 0; q < 9; ++q) o[3 + q] = acc[q];
 }
 
 // procBlock::UpdateAuxillaryVariables (procBlock.cpp:6171): temperature_ and

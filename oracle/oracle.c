@@ -43,6 +43,9 @@ typedef struct {
   double *wdist;         /* wallDist_ [cells_g]                 */
   double *temp, *visc;   /* temperature_, viscosity_ [cells_g]  */
   double *velgrad;       /* velocityGrad_ [cells_g][9]          */
+  double *grad18;        /* cell gradients of the last residual [cells][18], blocks with
+                            nonreflecting surfaces only (pressureGrad_, velocityGrad_ fed
+                            to the LODI terms, procBlock.cpp:2503-2505) */
   double *resid;         /* residual_ [cells][NEQ]              */
   double *specrad;       /* specRadius_ (flow part) [cells]     */
   double *dt;            /* dt_ [cells]                         */
@@ -72,6 +75,7 @@ struct ora_ctx {
   conn_t conn[MAXCONN];
   /* derived gas constants */
   double gamma, cp, cv, mu_ref, k_nondim, scaling, prandtl;
+  int have_time_n;   /* StoreOldSolution has run (consVarsN_ non-empty) */
   agx_exchange ex;   /* multi-rank transport (host buffers) */
   int have_ex;
 };
@@ -568,10 +572,23 @@ static void extrap_hold(const double *bnd, double factor, const double *in,
 
 /* GetGhostState ghostStates.cpp:62-689 (laminar, low-Re walls, reflecting
  * inlet/outlet) */
+/* what the nonreflecting (LODI) branches of GetGhostState read besides the interior
+ * state: dt and the state at time n of the adjacent cell, its pressure and velocity
+ * gradients, Mach mean / maximum over the surface (procBlock.cpp:6233-6262) */
+typedef struct { double dt, sn[NEQ], pg[3], vg[9], avg_mach, max_mach; } nr_data;
+static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
+                          const double *areaUnit, int surf, const agx_bc_state *d,
+                          int layer, double wallDist, const nr_data *nr, double *ghost);
 static int ghost_state(const ora_ctx *c, const double *interior, int bc,
                        const double *areaVec, int surf,
                        const agx_bc_state *d, int layer, double wallDist,
                        double *ghost) {
+  return ghost_state_nr(c, interior, bc, areaVec, surf, d, layer, wallDist, NULL, ghost);
+}
+static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
+                          const double *areaVec, int surf,
+                          const agx_bc_state *d, int layer, double wallDist,
+                          const nr_data *nr, double *ghost) {
   for (int e = 0; e < NEQ; ++e) ghost[e] = interior[e];
   const int isLower = surf % 2 == 1;
   double n[3];
@@ -639,7 +656,8 @@ static int ghost_state(const ora_ctx *c, const double *interior, int bc,
       memcpy(ghost, tmp, sizeof tmp);
     }
   } else if (bc == AGX_BC_INLET) {
-    if (d->is_nonreflecting) return fail("nonreflecting inlet: unsupported");
+    if (d->is_nonreflecting && !nr)
+      return fail("nonreflecting inlet needs the state at time n (StoreOldSolution)");
     double fs[NEQ] = {d->density * 1.0, d->velocity[0], d->velocity[1],
                       d->velocity[2], d->pressure};
     const double velIntNorm = dot3(interior + 1, n);
@@ -652,12 +670,27 @@ static int ghost_state(const ora_ctx *c, const double *interior, int bc,
       double velDiff[3] = {fs[1] - interior[1], fs[2] - interior[2],
                            fs[3] - interior[3]};
       ghost[4] = 0.5 * (fs[4] + interior[4] - rhoSoSInt * dot3(n, velDiff));
+      if (d->is_nonreflecting) {
+        /* LODI terms, ghostStates.cpp:435-462 */
+        const double sigma = 0.25;
+        const double rhoN = nr->sn[0], sosN = sos(c, nr->sn), rhoSoSN = rhoN * sosN;
+        const double deltaPressure = ghost[4] - nr->sn[4];
+        const double alpha = sigma * sosN / d->length_scale;
+        const double rhoNp1 = (rhoN + nr->dt * alpha * fs[0] + deltaPressure / (sosN * sosN)) /
+                              (1.0 + nr->dt * alpha);
+        ghost[0] = rhoNp1 * 1.0;
+        const double k = alpha * (1.0 - nr->max_mach * nr->max_mach);
+        for (int q = 0; q < 3; ++q)
+          ghost[1 + q] = (nr->sn[1 + q] + nr->dt * k * fs[1 + q] - n[q] * deltaPressure / rhoSoSN) /
+                         (1.0 + nr->dt * k);
+      } else {
       const double dP = fs[4] - ghost[4];
       const double rho = fs[0] - dP / (SoSInt * SoSInt);
       ghost[0] = rho * (fs[0] / fs[0]);
       ghost[1] = fs[1] - n[0] * dP / rhoSoSInt;
       ghost[2] = fs[2] - n[1] * dP / rhoSoSInt;
       ghost[3] = fs[3] - n[2] * dP / rhoSoSInt;
+      }
       double tmp[NEQ];
       extrap_hold(ghost, 2.0, interior, tmp);
       memcpy(ghost, tmp, sizeof tmp);
@@ -708,11 +741,42 @@ static int ghost_state(const ora_ctx *c, const double *interior, int bc,
       memcpy(ghost, tmp, sizeof tmp);
     }
   } else if (bc == AGX_BC_PRESSURE_OUTLET) {
-    if (d->is_nonreflecting) return fail("nonreflecting outlet: unsupported");
+    if (d->is_nonreflecting && !nr)
+      return fail("nonreflecting outlet needs the state at time n (StoreOldSolution)");
     const double pb = d->pressure;
     const double SoSInt = sos(c, interior);
     const double rhoSoSInt = interior[0] * SoSInt;
     ghost[4] = pb;
+    if (d->is_nonreflecting) {
+      /* LODI + transverse terms, ghostStates.cpp:614-643 */
+      const double *sn = nr->sn;
+      const double dvel[3] = {interior[1] - sn[1], interior[2] - sn[2], interior[3] - sn[3]};
+      const double deltaVel = dot3(dvel, n);
+      const double sigma = 0.25;
+      const double rhoN = sn[0], sosN = sos(c, sn), rhoSoSN = rhoN * sosN;
+      const double k = sigma * sosN * (1.0 - nr->max_mach * nr->max_mach) / d->length_scale;
+      const double beta = nr->avg_mach;
+      const double pgn = dot3(nr->pg, n), vnn = dot3(sn + 1, n);
+      double pGradT[3], velT[3], vgt[9], dVelN[3] = {0.0, 0.0, 0.0};
+      for (int q = 0; q < 3; ++q) {
+        pGradT[q] = nr->pg[q] - pgn * n[q];
+        velT[q] = sn[1 + q] - vnn * n[q];
+      }
+      double sum = 0.0;
+      for (int r = 0; r < 3; ++r) {          /* tensor::RemoveComponent, rows */
+        const double rn = dot3(nr->vg + 3 * r, n);
+        for (int q = 0; q < 3; ++q) vgt[3 * r + q] = nr->vg[3 * r + q] - rn * n[q];
+      }
+      for (int q = 0; q < 9; ++q) sum += vgt[q];                       /* tensor::Sum */
+      for (int r = 0; r < 3; ++r)                                     /* LinearCombination */
+        for (int q = 0; q < 3; ++q) dVelN[q] += vgt[3 * r + q] * n[r];
+      const double dVelT = sum - (dVelN[0] + dVelN[1] + dVelN[2]);
+      double tv[3];
+      for (int q = 0; q < 3; ++q) tv[q] = pGradT[q] - rhoSoSN * dVelN[q];
+      const double trans = -0.5 * (dot3(velT, tv) + c->gamma * sn[4] * dVelT);
+      ghost[4] = (sn[4] + rhoSoSN * deltaVel + nr->dt * k * pb - nr->dt * beta * trans) /
+                 (1.0 + nr->dt * k);
+    }
     const double dP = interior[4] - ghost[4];
     const double rho = interior[0] - dP / (SoSInt * SoSInt);
     ghost[0] = rho * (interior[0] / interior[0]);
@@ -787,6 +851,34 @@ static int assign_ghost_faces(ora_ctx *c, blk_t *b, int viscous) {
       /* slipWall (and viscous-pass viscousWall) reflect the layer-th
        * interior cell, the others extrapolate from the adjacent cell */
       const int srcCell = (bc == AGX_BC_SLIPWALL || viscous) ? iCell : aCell;
+      /* nonreflecting inlet / outlet: Mach mean and maximum over the surface
+       * (procBlock.cpp:6233-6262; local patch only, as the reference) */
+      const int is_nr = !viscous && q->state.is_nonreflecting &&
+                        (bc == AGX_BC_INLET || bc == AGX_BC_PRESSURE_OUTLET);
+      nr_data nr;
+      memset(&nr, 0, sizeof nr);
+      if (is_nr) {
+        if (!c->have_time_n)
+          return fail("nonreflecting boundary: the state at time n has not been stored");
+        double sum = 0.0, mx = -1.7976931348623157e308;
+        long cnt = 0;
+        for (int a2 = r2s; a2 < r2e; ++a2)
+          for (int a1 = r1s; a1 < r1e; ++a1) {
+            int i, j, k, fi, fj, fk;
+            surf_ijk(d3, aCell, a1, a2, &i, &j, &k);
+            surf_ijk(d3, bnd, a1, a2, &fi, &fj, &fk);
+            const double *ar = b->fa[d3] + 4 * FI(b, d3, fi, fj, fk);
+            const double sg = st % 2 == 1 ? -1.0 : 1.0;
+            const double nn3[3] = {sg * ar[0], sg * ar[1], sg * ar[2]};
+            const double *sb = b->state + NEQ * CI(b, i, j, k);
+            const double mach = dot3(sb + 1, nn3) / sos(c, sb);
+            if (mach > mx) mx = mach;
+            sum += mach;
+            ++cnt;
+          }
+        nr.avg_mach = sum / (double)cnt;
+        nr.max_mach = mx;
+      }
       for (int a2 = r2s; a2 < r2e; ++a2) {
         for (int a1 = r1s; a1 < r1e; ++a1) {
           int i, j, k, gi, gj, gk, fi, fj, fk;
@@ -797,8 +889,16 @@ static int assign_ghost_faces(ora_ctx *c, blk_t *b, int viscous) {
           double g[NEQ];
           int wi, wj, wk;                    /* procBlock.cpp:2813: aCell */
           surf_ijk(d3, aCell, a1, a2, &wi, &wj, &wk);
-          if (ghost_state(c, b->state + NEQ * CI(b, i, j, k), bc, area, st,
-                          &q->state, layer, b->wdist ? b->wdist[CI(b, wi, wj, wk)] : 0.0, g))
+          if (is_nr) {
+            const long pa = PI(b, wi, wj, wk);
+            nr.dt = b->dt[pa];
+            cons_to_prim(c, b->consn + NEQ * pa, nr.sn);
+            memcpy(nr.vg, b->grad18 + 18 * pa, sizeof nr.vg);
+            memcpy(nr.pg, b->grad18 + 18 * pa + 15, sizeof nr.pg);
+          }
+          if (ghost_state_nr(c, b->state + NEQ * CI(b, i, j, k), bc, area, st,
+                             &q->state, layer, b->wdist ? b->wdist[CI(b, wi, wj, wk)] : 0.0,
+                             is_nr ? &nr : NULL, g))
             return 1;
           memcpy(b->state + NEQ * CI(b, gi, gj, gk), g, sizeof g);
         }
@@ -1294,6 +1394,10 @@ static int calc_residual(ora_ctx *c, blk_t *b) {
   } else {
     update_aux(c, b);
   }
+  /* the cell gradients of this residual feed the nonreflecting ghost states of the
+   * next ghost fill (pressureGrad_, velocityGrad_: procBlock.cpp:1397-1449 / :6143) */
+  for (int sn = 0; sn < b->nsurf; ++sn)
+    if (b->surf[sn].state.is_nonreflecting) { cell_gradients(c, b, b->grad18); break; }
   return 0;
 }
 
@@ -1583,7 +1687,7 @@ int ora_ctx_create(int device, int rank, ora_ctx **out) {
 static void free_blk(blk_t *b) {
   double **ptrs[] = {&b->state, &b->fa[0], &b->fa[1], &b->fa[2], &b->vol,
                      &b->center, &b->wid[0], &b->wid[1], &b->wid[2],
-                     &b->wdist, &b->temp, &b->visc, &b->velgrad, &b->resid,
+                     &b->wdist, &b->temp, &b->visc, &b->velgrad, &b->grad18, &b->resid,
                      &b->specrad, &b->dt, &b->consn, &b->consnm1, &b->x,
                      &b->xold, &b->a, &b->ainv};
   for (size_t n = 0; n < sizeof ptrs / sizeof *ptrs; ++n) {
@@ -1655,6 +1759,7 @@ int ora_block_create(ora_ctx *c, const agx_block_geom *g, int *id) {
   b->temp = dup_arr(NULL, b->ncell_g);
   b->visc = dup_arr(NULL, b->ncell_g);
   b->velgrad = dup_arr(NULL, 9 * b->ncell_g);
+  b->grad18 = dup_arr(NULL, 18 * b->ncell);
   b->resid = dup_arr(NULL, NEQ * b->ncell);
   b->specrad = dup_arr(NULL, b->ncell);
   b->dt = dup_arr(NULL, b->ncell);
@@ -1780,6 +1885,7 @@ int ora_field_upload(ora_ctx *c, int id, int field, const double *in) {
 
 /* procBlock::AssignSolToTimeN / AssignSolToTimeNm1 procBlock.cpp:1037-1054 */
 int ora_store_time_n(ora_ctx *c, int also_nm1) {
+  c->have_time_n = 1;
   for (int n = 0; n < c->nblk; ++n) {
     blk_t *b = &c->blk[n];
     for (int k = 0; k < b->nk; ++k)

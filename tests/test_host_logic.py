@@ -202,3 +202,41 @@ def test_interblock_matches_single_block(oracle):
                           s2.download("state", 1)[2:-2, 2:-2, 2:-2]], axis=0)
     assert np.allclose(st1, st2, rtol=1e-12)
     s1.close(); s2.close()
+
+
+NONREFLECTING = {1: ("inlet", 6), 2: ("pressureOutlet", 7), 3: ("characteristic", 1),
+                 4: ("pressureOutlet", 7), 5: ("inlet", 6), 6: ("characteristic", 1)}
+
+
+def test_oracle_nonreflecting_uniform_flow_is_fixed_point(oracle):
+    """Nonreflecting inlet / pressure outlet (ghostStates.cpp:435-462, :614-643):
+    with the free stream of the BC states everywhere, dU = 0, the gradients vanish
+    and the LODI relaxation terms cancel, so the ghost states equal the free stream
+    and the flow does not move.  A perturbed start stays bounded and differs from
+    the reflecting variants of the same surfaces (the branch is really taken)."""
+    kw = dict(n=(9, 8, 7), stretch=1.1, bcs=NONREFLECTING, time_integration="bdf2",
+              nonlinear_iterations=2, dt=2.0e-5, dual_time_cfl=100.0, matrix_solver="lusgs")
+    case = synthetic.single_block_case(amplitude=0.0, **kw)
+    s = Solver(oracle, case)
+    s0 = s.download("state", 0).copy()
+    g = case.ng
+    for nn in range(2):
+        s.step(nn)
+    a = s.download("state", 0)
+    assert np.abs(a - s0)[g:-g, g:-g, g:-g].max() < 1e-12
+    assert np.abs(s.download("residual", 0)).max() < 1e-12
+    s.close()
+
+    moved = []
+    for nr in (True, False):
+        case = synthetic.single_block_case(amplitude=0.05, **kw)
+        if not nr:
+            for st in case.deck.bc_states:
+                st.params["nonreflecting"] = False
+        s = Solver(oracle, case)
+        for nn in range(3):
+            s.step(nn)
+        moved.append(s.download("state", 0)[g:-g, g:-g, g:-g].copy())
+        s.close()
+    assert np.isfinite(moved[0]).all() and moved[0][..., 0].min() > 0.5
+    assert np.abs(moved[0] - moved[1]).max() > 1e-6

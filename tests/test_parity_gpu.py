@@ -228,6 +228,11 @@ WALL_HEATFLUX = {3: ("viscousWall", 5), 1: ("characteristic", 1), 2: ("pressureO
                  4: ("characteristic", 1)}
 WALL_ISO = {3: ("viscousWall", 4), 4: ("viscousWall", 2),
             1: ("characteristic", 1), 2: ("characteristic", 1)}
+# nonreflecting (LODI) inlet and pressure outlet, ghostStates.cpp:435-462, :614-643
+NONREFLECTING = {1: ("inlet", 6), 2: ("pressureOutlet", 7), 3: ("characteristic", 1),
+                 4: ("pressureOutlet", 7), 5: ("inlet", 6), 6: ("characteristic", 1)}
+NONREFLECTING_WALL = {1: ("inlet", 6), 2: ("pressureOutlet", 7), 3: ("viscousWall", 2),
+                      4: ("characteristic", 1)}
 
 CASES = {
     "cfg2_muscl_roe_rk4": dict(n=(14, 12, 10), stretch=1.2, skew=0.01, bcs=SLIP,
@@ -276,6 +281,18 @@ CASES = {
     "visc_central4th_lusgs": dict(
         n=(11, 10, 9), stretch=1.15, bcs=WALL_J, equation_set="navierStokes",
         viscous_face_reconstruction="centralFourth",
+        time_integration="implicitEuler", matrix_solver="lusgs", cfl=10.0),
+    # no reference truth holds these branches (HIP-vs-oracle parity only); they read
+    # dt, the state at time n, the last residual's cell gradients and the surface's
+    # Mach mean / maximum (procBlock.cpp:2497-2515, :6233-6262)
+    "nonreflecting_bdf2_lusgs": dict(
+        n=(11, 10, 9), stretch=1.1, skew=0.01, bcs=NONREFLECTING, time_integration="bdf2",
+        nonlinear_iterations=2, dt=2.0e-5, dual_time_cfl=100.0, matrix_solver="lusgs"),
+    "nonreflecting_rk4": dict(
+        n=(10, 9, 8), stretch=1.1, bcs=NONREFLECTING, time_integration="rk4", cfl=0.5),
+    "nonreflecting_visc_lusgs": dict(
+        n=(10, 9, 8), stretch=1.15, bcs=NONREFLECTING_WALL, equation_set="navierStokes",
+        face_reconstruction="weno", limiter="none", inviscid_flux="ausm",
         time_integration="implicitEuler", matrix_solver="lusgs", cfl=10.0),
     "visc_central4th_weno_rk4": dict(
         n=(9, 10, 8), stretch=1.2, bcs=WALL_ISO, equation_set="navierStokes",
