@@ -122,13 +122,15 @@ struct agx_ctx {
   int spin_limit = 4000000;  // AGX_SPIN_LIMIT: polls before a waiting plane gives up
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
+  int mresid_split = 1;      // bands of diagonals per XCD in k_matrix_resid_d2 (AGX_MRESID_SPLIT)
   bool have_time_n = false;  // agx_store_time_n has run (nonreflecting BCs read consVarsN)
   // agx_iterate fills the ghost cells for the NEXT call right after the update,
   // behind the norm read-back the host waits for, so that the GPU does not idle
   // while the host turns the iteration around
   bool in_iterate = false, ghosts_prefilled = false;
   hipEvent_t norm_event = nullptr;
-  bool consn_pending = false;   // AssignSolToTimeN deferred into the next fused stage-0 launch
+  bool consn_pending = false;   // AssignSolToTimeN deferred into the first residual launch of the step
+  bool state_is_time_n = false; // nothing has changed the state since agx_store_time_n
   long fused_parts = 0;
   // timing: hipEvent pairs recorded on the library's stream around each
   // kernel group, resolved lazily in agx_timing_get (no sync while running)
@@ -603,6 +605,7 @@ int bc_pass(agx_ctx* c, bool faces, int viscous) {
       if (!viscous && blk.nr_max > 0) {
         if (!c->have_time_n)
           return fail("nonreflecting boundary: the state at time n has not been stored");
+        if (flush_consn(c)) return 1;   // (its ghost states read consVarsN)
         hipLaunchKernelGGL(k_nr_mach, dim3(b.nsurf), dim3(256), 0, c->stream, b, c->gas);
       }
       if (nmax > 0)
@@ -640,6 +643,7 @@ int fill_ghosts(agx_ctx* c) {
   return agx_phase_bc_edges(c);
 }
 int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
+  c->state_is_time_n = false;
   const double alpha[4] = {0.25, 1.0 / 3.0, 0.5, 1.0};   // procBlock.cpp:938
   if (mode != 2 && c->fused_pending) {
     // the marching kernel already advanced the state into the second buffer
@@ -745,6 +749,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_EAGER_GHOSTS")) c->eager_ghosts = atoi(w) != 0;
     if (const char* w = getenv("AGX_LUSGS")) c->lusgs_mode = !strcmp(w, "plane") ? 0 : 1;
     if (const char* w = getenv("AGX_SPIN_LIMIT")) c->spin_limit = std::max(1, atoi(w));
+    if (const char* w = getenv("AGX_MRESID_SPLIT")) c->mresid_split = std::min(64, std::max(1, atoi(w)));
   }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
   HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
@@ -1001,6 +1006,13 @@ int agx_conn_create(agx_ctx* c, const agx_connection* cc, int* conn_id) {
   return 0;
 }
 
+// workgroups of k_matrix_resid_d2: 8 XCDs x mresid_split bands x chunks per band x nk
+long mresid_wgs(const agx_ctx* c, const BlockDev& b) {
+  const long nchunk = ((long)b.d2.Pi * b.d2.Pj + 255) / 256;
+  const long bands = 8L * c->mresid_split;
+  return bands * ((nchunk + bands - 1) / bands) * b.nk;
+}
+
 int agx_setup_finalize(agx_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
   const int ng = c->cfg.n_ghost;
@@ -1011,8 +1023,7 @@ int agx_setup_finalize(agx_ctx* c) {
     max_parts = std::max(max_parts, (long)g.x * g.y * g.z);
     march_parts += march_plan(c, blk.d).nparts;
     if (blk.d.d2.base)    // k_matrix_resid_d2: one partial per 256 plane positions
-      max_parts = std::max(max_parts,
-                           8 * (((((long)blk.d.d2.Pi * blk.d.d2.Pj + 255) / 256) + 7) / 8) * blk.d.nk);
+      max_parts = std::max(max_parts, mresid_wgs(c, blk.d));
   }
   max_parts = std::max(max_parts, march_parts);
   for (auto& k : c->conns) {
@@ -1116,6 +1127,7 @@ int agx_setup_finalize(agx_ctx* c) {
 
 int agx_state_upload(agx_ctx* c, int id, const double* state) {
   c->ghosts_prefilled = false;
+  c->state_is_time_n = false;
   if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
@@ -1191,6 +1203,7 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
 }
 int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
   c->ghosts_prefilled = false;
+  c->state_is_time_n = false;
   if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
@@ -1210,7 +1223,8 @@ int agx_store_time_n(agx_ctx* c, int also_nm1) {
   // separate 5-load/5-store pass); anything else that touches consVarsN or the
   // state first calls flush_consn().
   static const bool lazy = !(getenv("AGX_NO_LAZY_CONSN") && atoi(getenv("AGX_NO_LAZY_CONSN")));
-  if (lazy && !also_nm1 && can_fuse(c) && all_tile_ok(c)) { c->consn_pending = true; return 0; }
+  c->state_is_time_n = true;
+  if (lazy && !also_nm1 && !c->use_gather && all_tile_ok(c)) { c->consn_pending = true; return 0; }
   for (auto& blk : c->blocks)
     hipLaunchKernelGGL(k_store_time_n, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
                        0, c->stream, blk.d, c->gas, also_nm1);
@@ -1226,7 +1240,7 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
   if (c->cfg.dt_nondim <= 0.0 && cfl <= 0.0)
     return fail("Neither dt or cfl was specified!");   // procBlock.cpp:813-816
   const bool fuse = can_fuse(c);
-  const int store_consn = fuse && all_tile_ok(c) && c->consn_pending && mm == 0;
+  const int store_consn = !c->use_gather && all_tile_ok(c) && c->consn_pending && mm == 0;
   if (store_consn) c->consn_pending = false;
   else if (flush_consn(c)) return 1;
   {
@@ -1304,6 +1318,7 @@ int agx_phase_explicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
 
 int agx_phase_implicit_begin(agx_ctx* c) {
   Timer t(c, G_PREPARE);
+  c->sp.un_is_u = c->state_is_time_n ? 1 : 0;   // (read by every rhs_b of this iteration)
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
     if (b.d2.base) {
@@ -1368,11 +1383,10 @@ int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       const BlockDev& b = c->blocks[n].d;
       if (b.d2.base) {
-        // (position chunk, k) pairs dealt to the XCDs column by column, see the kernel
-        const long nchunk = ((long)b.d2.Pi * b.d2.Pj + 255) / 256;
-        const long nwg = 8 * ((nchunk + 7) / 8) * b.nk;
+        // (position chunk, k) pairs dealt to the XCDs band by band, see the kernel
+        const long nwg = mresid_wgs(c, b);
         hipLaunchKernelGGL(k_matrix_resid_d2, dim3((unsigned)nwg), dim3(256), 0, c->stream, b,
-                           c->gas, c->sp, c->partials);
+                           c->gas, c->sp, c->mresid_split, c->partials);
         if (reduce_norms(c, n, nwg)) return 1;
         continue;
       }

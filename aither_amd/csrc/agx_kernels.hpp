@@ -104,6 +104,10 @@ struct SolverDev {   // scalar run-time parameters of agx_config
   double kappa, theta, zeta, relax, dual_time_cfl, dt_fixed, visc_cfl_coeff;
   int viscous, implicit, bdf2, requires_init, time_integration;
   int roe_jacobian;    // inviscidFluxJacobian: approximateRoe (RoeOffDiagonal)
+  // the state has not changed since AssignSolToTimeN: U - U_n of the implicit
+  // right-hand side (procBlock.cpp:1037, linearSolver.cpp:370) is exactly zero and
+  // consVarsN need not be read
+  int un_is_u;
 };
 
 __device__ __forceinline__ void load5(double* const* p, long q, double* s) {
@@ -239,7 +243,7 @@ struct MarchArgs {
   int kchunk;              // k planes per workgroup
   int mode;                // FUSE: 0 explicit Euler, 1 RK stage
   double alpha;            // RK stage coefficient
-  int store_consn;         // fused stage 0: also write cons(state) to consVarsN
+  int store_consn;         // first residual of a time step: also write cons(state) to consVarsN
   int ablate;              // diagnostic (AGX_ABLATE): 1 no flux math, 2 no
                            // reconstruction, 4 no stores, 8 no cons->prim,
                            // 16 no spectral radius, 32 idle halo waves,
@@ -832,6 +836,12 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
           b.stb(PL_SPECRAD, qb, sr);
           if (sp.implicit) b.stb(PL_A, qb, sr);
           if (!sp.viscous) b.stb(PL_DT, qb, dt);
+          if (FUSE == 0 && ma.store_consn) {   // AssignSolToTimeN (procBlock.cpp:1037) rides along
+            double u0[AGX_NEQ];
+            prim_to_cons(g, sc, u0);
+#pragma unroll
+            for (int e = 0; e < AGX_NEQ; ++e) b.stb(PL_CONSN + e, qb, u0[e]);
+          }
         }
         if (FUSE) {
           double u[AGX_NEQ], ns[AGX_NEQ];
@@ -1695,16 +1705,23 @@ k_store_time_n(BlockDev b, GasDev g, int also_nm1) {
 // procBlock.cpp:1010-1035
 __device__ __forceinline__ void rhs_b(const BlockDev& b, const GasDev& g,
                                       const SolverDev& sp, long q, double* out) {
-  double s[AGX_NEQ], u[AGX_NEQ], un[AGX_NEQ], r[AGX_NEQ];
+  double r[AGX_NEQ];
+  load5(b.resid, q, r);
+  const double thetaInv = 1.0 / sp.theta;
+  if (sp.un_is_u && !sp.bdf2) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) out[e] = -thetaInv * r[e] - 0.0;
+    return;
+  }
+  double s[AGX_NEQ], u[AGX_NEQ], un[AGX_NEQ];
   load5(b.state, q, s);
   load5(b.consn, q, un);
-  load5(b.resid, q, r);
   prim_to_cons(g, s, u);
   const double vdt = b.vol[q] / (b.dt[q] * sp.theta);
   const double cN = vdt * (1.0 + sp.zeta);
-  const double thetaInv = 1.0 / sp.theta;
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) out[e] = -thetaInv * r[e] - cN * (u[e] - un[e]);
+  for (int e = 0; e < AGX_NEQ; ++e)
+    out[e] = -thetaInv * r[e] - (sp.un_is_u ? 0.0 : cN * (u[e] - un[e]));
   if (sp.bdf2) {
     double um[AGX_NEQ];
     load5(b.consnm1, q, um);
