@@ -192,8 +192,10 @@ class InputDeck:
             bad.append("thermallyPerfect")
         if self.multigrid_levels != 1:
             bad.append("multigrid")
-        if self.matrix_solver not in ("lusgs", "dplur"):
+        if self.matrix_solver not in ("lusgs", "dplur", "blusgs", "bdplur"):
             bad.append(f"matrixSolver {self.matrix_solver}")
+        if self.matrix_solver in ("blusgs", "bdplur") and self.inv_flux_jac != "rusanov":
+            bad.append("block-matrix solver with inviscidFluxJacobian approximateRoe")
         if self.inv_flux_jac not in ("rusanov", "approximateRoe"):
             bad.append(f"inviscidFluxJacobian {self.inv_flux_jac}")
         if self.viscous_face_reconstruction not in ("central", "centralFourth"):

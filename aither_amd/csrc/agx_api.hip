@@ -41,6 +41,7 @@ struct Block {
   int global_pos = 0;
   double* slab = nullptr;
   double* d2 = nullptr;       // D2 arrays of the LU-SGS path (agx_lusgs.hpp)
+  double* blockmat = nullptr; // block-matrix solvers: a_ | aInv_ | velocityGrad_ planes
   int* d2_tab = nullptr;      // device: dstart[Pi + Pj] | ij_of_pos[Pi * Pj]
   std::vector<int> dstart;    // host copy (halo index maps)
   int* kp_mem = nullptr;      // k_lusgs_kp: progress flag per k-plane | ticket
@@ -345,6 +346,8 @@ int check_device_error(agx_ctx* c) {
     const int code = *c->err_host;
     *c->err_host = 0;
     hipMemsetAsync(c->err_dev, 0, sizeof(int), c->stream);
+    if (code == 3)
+      return fail("Singular matrix in Gauss-Jordan elimination!");   // matrix.cpp:81
     if (code == 2)
       return fail("LU-SGS pipeline: a k-plane waited beyond the spin limit for its "
                   "predecessor (AGX_LUSGS=plane selects the launch-per-hyperplane form)");
@@ -453,6 +456,34 @@ void launch_inv(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
   }
 }
 
+// block-matrix solvers: the inviscid part of the main diagonal (k_block_diag_inv)
+template <int RECON>
+void launch_block_diag_lim(agx_ctx* c, const BlockDev& b) {
+  const dim3 grid = cell_grid(b, CELL_BLOCK);
+  switch (RECON == AGX_RECON_MUSCL ? c->cfg.limiter : AGX_LIMITER_NONE) {
+    case AGX_LIMITER_VANALBADA:
+      hipLaunchKernelGGL((k_block_diag_inv<RECON, AGX_LIMITER_VANALBADA>), grid, CELL_BLOCK, 0,
+                         c->stream, b, c->gas, c->sp);
+      break;
+    case AGX_LIMITER_MINMOD:
+      hipLaunchKernelGGL((k_block_diag_inv<RECON, AGX_LIMITER_MINMOD>), grid, CELL_BLOCK, 0,
+                         c->stream, b, c->gas, c->sp);
+      break;
+    default:
+      hipLaunchKernelGGL((k_block_diag_inv<RECON, AGX_LIMITER_NONE>), grid, CELL_BLOCK, 0,
+                         c->stream, b, c->gas, c->sp);
+      break;
+  }
+}
+void launch_block_diag(agx_ctx* c, const BlockDev& b) {
+  switch (c->cfg.recon) {
+    case AGX_RECON_CONSTANT: launch_block_diag_lim<AGX_RECON_CONSTANT>(c, b); break;
+    case AGX_RECON_MUSCL: launch_block_diag_lim<AGX_RECON_MUSCL>(c, b); break;
+    case AGX_RECON_WENO: launch_block_diag_lim<AGX_RECON_WENO>(c, b); break;
+    default: launch_block_diag_lim<AGX_RECON_WENOZ>(c, b); break;
+  }
+}
+
 bool can_fuse(const agx_ctx* c) {
   // (nonreflecting surfaces read the gradients of the residual's own state after it)
   for (const auto& blk : c->blocks) if (blk.nr_max > 0) return false;
@@ -460,6 +491,12 @@ bool can_fuse(const agx_ctx* c) {
 }
 
 // the D2 LU-SGS path (agx_lusgs.hpp) serves scalar LU-SGS unless AGX_LUSGS=plane
+bool is_block_solver(const agx_ctx* c) {   // input::IsBlockMatrix input.cpp:713
+  return c->cfg.matrix_solver == AGX_SOLVER_BLUSGS || c->cfg.matrix_solver == AGX_SOLVER_BDPLUR;
+}
+bool is_lusgs_solver(const agx_ctx* c) {   // input.cpp:847
+  return c->cfg.matrix_solver == AGX_SOLVER_LUSGS || c->cfg.matrix_solver == AGX_SOLVER_BLUSGS;
+}
 bool use_d2(const agx_ctx* c) {
   // (the Roe off-diagonal needs the state on both sides of a face: served by the
   // hyperplane-per-launch form on the SoA planes)
@@ -766,6 +803,7 @@ void agx_ctx_destroy(agx_ctx* c) {
   for (auto& b : c->blocks) {
     if (b.slab) hipFree(b.slab);
     if (b.d2) hipFree(b.d2);
+    if (b.blockmat) hipFree(b.blockmat);
     if (b.d2_tab) hipFree(b.d2_tab);
     if (b.kp_mem) hipFree(b.kp_mem);
     if (b.surf_dev) hipFree(b.surf_dev);
@@ -835,9 +873,12 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
   if (cfg->viscous_recon == AGX_VISC_RECON_CENTRAL_4TH && cfg->n_ghost < 2)
     return fail("centralFourth needs two ghost layers (input::NumberGhostLayers, "
                 "input.cpp:1127-1143)");
-  if (cfg->matrix_solver != AGX_SOLVER_LUSGS && cfg->matrix_solver != AGX_SOLVER_DPLUR)
-    return fail("matrix_solver %d: the block-matrix solvers (blusgs, bdplur) are not built",
+  if (cfg->matrix_solver < AGX_SOLVER_LUSGS || cfg->matrix_solver > AGX_SOLVER_BDPLUR)
+    return fail("matrix_solver %d is not one of lusgs / dplur / blusgs / bdplur",
                 cfg->matrix_solver);
+  if ((cfg->matrix_solver == AGX_SOLVER_BLUSGS || cfg->matrix_solver == AGX_SOLVER_BDPLUR) &&
+      cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE)
+    return fail("block-matrix solvers are built for inviscidFluxJacobian rusanov only");
   c->cfg = *cfg;
   derive_gas(*cfg, c->gas);
   SolverDev& sp = c->sp;
@@ -852,7 +893,9 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
   sp.implicit = cfg->time_integration >= AGX_TIME_IMPLICIT_EULER;
   sp.bdf2 = cfg->time_integration == AGX_TIME_BDF2;
   // input::MatrixRequiresInitialization input.cpp:1120-1125
-  sp.requires_init = cfg->matrix_solver == AGX_SOLVER_DPLUR || cfg->matrix_sweeps > 1;
+  sp.requires_init = cfg->matrix_solver == AGX_SOLVER_DPLUR ||
+                     cfg->matrix_solver == AGX_SOLVER_BDPLUR || cfg->matrix_sweeps > 1;
+  sp.block = (cfg->matrix_solver == AGX_SOLVER_BLUSGS || cfg->matrix_solver == AGX_SOLVER_BDPLUR) ? 1 : 0;
   sp.time_integration = cfg->time_integration;
   sp.roe_jacobian = cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE;
   c->have_cfg = true;
@@ -894,6 +937,15 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
     for (int cc = 0; cc < 4; ++cc) d.fa[q][cc] = pl(PL_FA + 4 * q + cc);
   }
   b.state_is_a = true;
+  if (c->sp.implicit && is_block_solver(c)) {
+    // a_, aInv_ (25 planes each) and velocityGrad_ (9) of the block-matrix solvers
+    const size_t n = (size_t)d.nplane * (2 * AGX_NJ + 9);
+    HIPCHK(hipMalloc((void**)&b.blockmat, sizeof(double) * n));
+    HIPCHK(hipMemsetAsync(b.blockmat, 0, sizeof(double) * n, c->stream));
+    d.am = b.blockmat;
+    d.aminv = b.blockmat + (size_t)d.nplane * AGX_NJ;
+    d.vg = b.blockmat + (size_t)d.nplane * 2 * AGX_NJ;
+  }
   if (use_d2(c) && std::min(d.ni, d.nj) > KP_MAX_DIAG)
     return fail("LU-SGS: a block with min(ni, nj) = %d exceeds the %d cells per diagonal "
                 "the sweep kernel holds in LDS (AGX_LUSGS=plane has no such limit)",
@@ -1016,6 +1068,10 @@ long mresid_wgs(const agx_ctx* c, const BlockDev& b) {
 int agx_setup_finalize(agx_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
   const int ng = c->cfg.n_ghost;
+  if (c->sp.implicit && c->sp.block && c->sp.viscous && !c->conns.empty())
+    return fail("block-matrix solvers with viscous terms are built for blocks without "
+                "connection surfaces: the velocity gradients of the cells across a "
+                "connection (SwapEddyViscAndGradients, gridLevel.cpp:343-368) are not exchanged");
   long max_parts = 1, max_halo = 1;
   long march_parts = 0;
   for (auto& blk : c->blocks) {
@@ -1259,6 +1315,7 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
       ma.ablate = getenv("AGX_ABLATE") ? atoi(getenv("AGX_ABLATE")) : 0;
       launch_inv(c, blk.d, cfl, fuse, ma, mp);
       off += mp.nparts;
+      if (c->sp.implicit && c->sp.block) launch_block_diag(c, blk.d);
     }
   }
   HIPCHK(hipGetLastError());
@@ -1297,6 +1354,11 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
         hipLaunchKernelGGL(k_visc_tile, dim3(gx, gy, nz), dim3(VT_L, VT_R), 0, c->stream,
                            make_slab(vb), c->gas, c->sp, cfl, kchunk);
       }
+    if (c->sp.implicit && c->sp.block)
+      for (auto& blk : c->blocks)
+        hipLaunchKernelGGL(k_block_diag_visc, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK, 0,
+                           c->stream, blk.d, c->gas, c->sp,
+                           c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH ? 1 : 0);
     HIPCHK(hipGetLastError());
   }
   // the gradients of this residual's state feed the nonreflecting ghost states of
@@ -1334,7 +1396,7 @@ int agx_phase_implicit_begin(agx_ctx* c) {
       hipLaunchKernelGGL(k_zero5, dim3((b.nplane + 255) / 256), dim3(256), 0,
                          c->stream, planes(b.x), b.nplane);
     hipLaunchKernelGGL(k_implicit_begin, cell_grid(b, CELL_BLOCK), CELL_BLOCK, 0,
-                       c->stream, b, c->gas, c->sp);
+                       c->stream, b, c->gas, c->sp, c->err_dev);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -1346,7 +1408,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
   bool swept = false;
   for (auto& blk : c->blocks) {
     BlockDev& b = blk.d;
-    if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
+    if (is_lusgs_solver(c)) {
       if (lusgs_sweep(c, blk, true, full)) return 1;
       swept = true;
     } else {
@@ -1365,7 +1427,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
 }
 
 int agx_phase_relax_backward(agx_ctx* c, int sweep) {
-  if (c->cfg.matrix_solver != AGX_SOLVER_LUSGS) return 0;
+  if (!is_lusgs_solver(c)) return 0;
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
   for (auto& blk : c->blocks) {
@@ -1632,7 +1694,7 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
     for (int s = 0; s < c->cfg.matrix_sweeps; ++s) {
       if (agx_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
       if (agx_phase_relax_forward(c, s)) return 1;
-      if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
+      if (is_lusgs_solver(c)) {
         if (agx_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
         if (agx_phase_relax_backward(c, s)) return 1;
       }

@@ -453,6 +453,196 @@ __device__ __forceinline__ void off_diagonal(const GasDev& g, bool viscous,
     out[e] = 0.5 * area[3] * (fn[e] - fo[e]) + sg * du[e] * sr;
 }
 
+// ---- block-matrix solvers (blusgs / bdplur): 5 x 5 flow Jacobians, row major ----
+constexpr int AGX_NJ = AGX_NEQ * AGX_NEQ;
+// fluxJacobian::InvFluxJacobian fluxJacobian.hpp:483-560 (one species, mf = 1)
+__device__ inline void inv_flux_jacobian(const GasDev& g, const double* s, const double* area,
+                                         double* J) {
+  const double* n = area;
+  const double vn = dot3(s + 1, n);
+  const double gm1 = g.gamma - 1.0;
+  const double phi = 0.5 * gm1 * dot3(s + 1, s + 1);
+  double u[AGX_NEQ];
+  prim_to_cons(g, s, u);
+  const double a1 = g.gamma * (u[4] / s[0]) - phi;    // primitive::Energy
+  const double a3 = g.gamma - 2.0;
+#pragma unroll
+  for (int q = 0; q < AGX_NJ; ++q) J[q] = 0.0;
+  J[0] = vn * (1.0 - 1.0);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    J[1 + q] = 1.0 * n[q];
+    J[AGX_NEQ * (1 + q)] = phi * n[q] - s[1 + q] * vn;
+  }
+  J[AGX_NEQ * 4] = vn * (phi - a1);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      J[AGX_NEQ * (1 + r) + 1 + c] = r == c ? vn - a3 * n[c] * s[1 + c]
+                                            : s[1 + r] * n[c] - gm1 * s[1 + c] * n[r];
+    J[AGX_NEQ * 4 + 1 + c] = a1 * n[c] - gm1 * s[1 + c] * vn;
+    J[AGX_NEQ * (1 + c) + 4] = gm1 * n[c];
+  }
+  J[AGX_NEQ * 4 + 4] = g.gamma * vn;
+  const double h = 0.5 * area[3];
+#pragma unroll
+  for (int q = 0; q < AGX_NJ; ++q) J[q] *= h;
+}
+// fluxJacobian::RusanovFluxJacobian :446-479 with InvFaceSpectralRadius
+// spectralRadius.hpp:67-80
+__device__ inline void rusanov_flux_jacobian(const GasDev& g, const double* s, const double* area,
+                                             bool positive, double* J) {
+  const double sr = 0.5 * area[3] * (fabs(dot3(s + 1, area)) + sound_speed(g, s));
+  inv_flux_jacobian(g, s, area, J);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) J[AGX_NEQ * e + e] += positive ? sr : -sr;
+}
+// fluxJacobian::ApproxTSLJacobian :660-758 (laminar, one species) times
+// DelprimitiveDelConservative :613-656; TauNormal utility.cpp:426-436.  vg[3 r + c]:
+// velocity gradient (only its trace and symmetric part enter)
+__device__ inline void tsl_jacobian(const GasDev& g, const double* s, double lam_visc,
+                                    const double* area, double dist, bool left, const double* vg,
+                                    double* J) {
+  const double t = temperature(g, s);
+  const double mu = g.scaling * lam_visc;
+  const double* n = area;
+  const double vn = dot3(s + 1, n);
+  const double rho = s[0];
+  const double k = conductivity(g, t) * g.scaling;
+  const double lambda = 0.0 - (2.0 / 3.0) * mu;
+  const double trace = vg[0] + vg[4] + vg[8];
+  double tau[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double mm = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) mm += (vg[3 * r + q] + vg[3 * q + r]) * n[q];
+    tau[r] = lambda * trace * n[r] + mu * mm;
+  }
+  const double fac = left ? -1.0 : 1.0;
+  const double third = 1.0 / 3.0;
+  double T[AGX_NJ], P[AGX_NJ];
+#pragma unroll
+  for (int q = 0; q < AGX_NJ; ++q) { T[q] = 0.0; P[q] = 0.0; }
+  T[AGX_NEQ * 4] = -k * t / (mu * rho) + 0.0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      T[AGX_NEQ * (1 + r) + 1 + c] = third * n[c] * n[r] + (r == c ? 1.0 : 0.0);
+    T[AGX_NEQ * 4 + 1 + c] = fac * 0.5 * dist / mu * tau[c] + third * n[c] * vn + s[1 + c];
+  }
+  T[AGX_NEQ * 4 + 4] = k / (mu * rho);
+  const double sc = area[3] * mu / dist;
+#pragma unroll
+  for (int q = 0; q < AGX_NJ; ++q) T[q] *= sc;
+  const double gm1 = g.gamma - 1.0, ir = 1.0 / rho;
+  P[0] = 1.0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    P[AGX_NEQ * (1 + q)] = -ir * s[1 + q];
+    P[AGX_NEQ * (1 + q) + 1 + q] = ir;
+    P[AGX_NEQ * 4 + 1 + q] = -gm1 * s[1 + q];
+  }
+  P[AGX_NEQ * 4] = 0.5 * gm1 * dot3(s + 1, s + 1);
+  P[AGX_NEQ * 4 + 4] = gm1;
+#pragma unroll
+  for (int q = 0; q < AGX_NJ; ++q) J[q] = 0.0;
+#pragma unroll
+  for (int c = 0; c < AGX_NEQ; ++c)          // MatrixMultiply matrix.cpp:193-207
+#pragma unroll
+    for (int r = 0; r < AGX_NEQ; ++r)
+#pragma unroll
+      for (int i = 0; i < AGX_NEQ; ++i) J[AGX_NEQ * r + i] += T[AGX_NEQ * r + c] * P[AGX_NEQ * c + i];
+}
+// MatrixInverse matrix.cpp:57-103 (Gauss-Jordan with row exchanges); m becomes its
+// inverse; returns false for a singular matrix.  Fully unrolled, so the 50 doubles
+// stay in registers (row exchanges are conditional swaps).
+__device__ inline bool matrix_inverse5(double* m) {
+  constexpr int N = AGX_NEQ;
+  double I[AGX_NJ];
+#pragma unroll
+  for (int q = 0; q < AGX_NJ; ++q) I[q] = (q / N == q % N) ? 1.0 : 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    // FindMaxInColumn(mat, size, r, r, size - 1)
+    double mx = 0.0;
+    int rp = 0;
+#pragma unroll
+    for (int ii = r; ii < N; ++ii)
+      if (fabs(m[ii * N + r]) > mx) { mx = fabs(m[ii * N + r]); rp = ii; }
+#pragma unroll
+    for (int ii = r + 1; ii < N; ++ii) {       // swap rows r and rp (rp == 0 only if column is 0)
+      const bool sw = rp == ii;
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const double a = m[r * N + q], bq = m[ii * N + q];
+        m[r * N + q] = sw ? bq : a;
+        m[ii * N + q] = sw ? a : bq;
+        const double c = I[r * N + q], dq = I[ii * N + q];
+        I[r * N + q] = sw ? dq : c;
+        I[ii * N + q] = sw ? c : dq;
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < r; ++ii) {
+      const double factor = m[r * N + ii] / m[ii * N + ii];
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        m[r * N + q] = m[r * N + q] - factor * m[ii * N + q];
+        I[r * N + q] = I[r * N + q] - factor * I[ii * N + q];
+      }
+    }
+    if (m[r * N + r] == 0.0) ok = false;
+    const double nf = 1.0 / m[r * N + r];
+#pragma unroll
+    for (int q = r; q < N; ++q) m[r * N + q] *= nf;
+#pragma unroll
+    for (int q = 0; q < N; ++q) I[r * N + q] *= nf;
+  }
+#pragma unroll
+  for (int r = N - 2; r >= 0; --r)
+#pragma unroll
+    for (int ii = N - 1; ii > r; --ii) {
+      const double factor = m[r * N + ii];
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        m[r * N + q] = m[r * N + q] - factor * m[ii * N + q];
+        I[r * N + q] = I[r * N + q] - factor * I[ii * N + q];
+      }
+    }
+#pragma unroll
+  for (int q = 0; q < AGX_NJ; ++q) m[q] = I[q];
+  return ok;
+}
+// ArrayMultiplication fluxJacobian.hpp:50-87 (block branch)
+__device__ __forceinline__ void mat_vec5(const double* m, const double* v, double* out) {
+#pragma unroll
+  for (int r = 0; r < AGX_NEQ; ++r) {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < AGX_NEQ; ++c) a += m[AGX_NEQ * r + c] * v[c];
+    out[r] = a;
+  }
+}
+// RusanovBlockOffDiagonal fluxJacobian.cpp:164-194
+__device__ inline void block_off_diagonal(const GasDev& g, bool viscous, const double* s,
+                                          const double* du, const double* area, double mu,
+                                          double dist, bool positive, const double* vg,
+                                          double* out) {
+  double J[AGX_NJ];
+  rusanov_flux_jacobian(g, s, area, positive, J);
+  if (viscous) {
+    double V[AGX_NJ];
+    tsl_jacobian(g, s, mu, area, dist, positive, vg, V);
+#pragma unroll
+    for (int q = 0; q < AGX_NJ; ++q) J[q] = positive ? J[q] - V[q] : J[q] + V[q];
+  }
+  mat_vec5(J, du, out);
+}
+
 // ---- ghost states, ghostStates.cpp:62-708 ----------------------------------
 __device__ __forceinline__ void extrap_hold(const double* bnd, double factor,
                                             const double* in, double* out) {

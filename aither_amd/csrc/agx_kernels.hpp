@@ -36,6 +36,11 @@ struct BlockDev {
   double* xold[AGX_NEQ];      // dplur copy              linearSolver.cpp:487
   double* a;                  // linearSolver::a_ (scalar flow part)
   double* ainv;               // linearSolver::aInv_
+  // block-matrix solvers (null otherwise): 25 planes each of a_ / aInv_ (entry e of
+  // cell q at [e * nplane + q], row major) and 9 planes of velocityGrad_
+  double* am;
+  double* aminv;
+  double* vg;
   double* wdist;              // wallDist_                procBlock.hpp:88
   D2Dev d2;                   // diagonal-ordered arrays of the LU-SGS path (agx_lusgs.hpp)
   const agx_bc_surface* surf; // boundaryConditions      boundaryConditions.hpp:231
@@ -108,6 +113,7 @@ struct SolverDev {   // scalar run-time parameters of agx_config
   // right-hand side (procBlock.cpp:1037, linearSolver.cpp:370) is exactly zero and
   // consVarsN need not be read
   int un_is_u;
+  int block;           // input::IsBlockMatrix (blusgs / bdplur)
 };
 
 __device__ __forceinline__ void load5(double* const* p, long q, double* s) {
@@ -130,13 +136,10 @@ __device__ __forceinline__ void load_area(const BlockDev& b, int d, long q, doub
 // so no atomics and a reproducible sum.  Also forms the inviscid cell
 // spectral radius, the scalar implicit diagonal and (inviscid runs) dt.
 // Counterpart of procBlock::CalcInvFluxI/J/K procBlock.cpp:384-795.
-template <int RECON, int LIM, int FLUX>
-__device__ __forceinline__ void face_flux_1d(const GasDev& g, double kappa,
-                                             const double (*st)[AGX_NEQ],
-                                             const double* w, int c,
-                                             const double* area, double* f) {
+template <int RECON, int LIM>
+__device__ __forceinline__ void face_states_1d(double kappa, const double (*st)[AGX_NEQ],
+                                               const double* w, int c, double* l, double* r) {
   // st[m], w[m]: 1-D stencil; the face lies between entries c-1 and c
-  double l[AGX_NEQ], r[AGX_NEQ];
   if (RECON == AGX_RECON_CONSTANT) {
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) { l[e] = st[c - 1][e]; r[e] = st[c][e]; }
@@ -166,7 +169,60 @@ __device__ __forceinline__ void face_flux_1d(const GasDev& g, double kappa,
                                             st[c][e], st[c - 1][e], st[c - 2][e]);
     }
   }
+}
+template <int RECON, int LIM, int FLUX>
+__device__ __forceinline__ void face_flux_1d(const GasDev& g, double kappa,
+                                             const double (*st)[AGX_NEQ],
+                                             const double* w, int c,
+                                             const double* area, double* f) {
+  double l[AGX_NEQ], r[AGX_NEQ];
+  face_states_1d<RECON, LIM>(kappa, st, w, c, l, r);
   inviscid_flux<FLUX>(g, l, r, area, f);
+}
+
+// Block-matrix solvers: inviscid part of the main diagonal of a cell,
+// + RusanovFluxJacobian(left face state) of its upper faces, - RusanovFluxJacobian(
+// right face state) of its lower faces (procBlock.cpp:452-457, :481-486 and the j / k
+// twins); the face states are reconstructed again here, one thread per cell.
+template <int RECON, int LIM>
+__global__ void __launch_bounds__(256)
+k_block_diag_inv(BlockDev b, GasDev g, SolverDev sp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  constexpr int H = RECON == AGX_RECON_CONSTANT ? 1
+                    : (RECON == AGX_RECON_MUSCL ? 2 : 3);
+  constexpr int NS = 2 * H + 1;
+  const long q = b.idx(i, j, k);
+  double D[AGX_NJ];
+#pragma unroll
+  for (int e = 0; e < AGX_NJ; ++e) D[e] = 0.0;
+  for (int d = 0; d < 3; ++d) {
+    const long s = b.stride(d);
+    double st[NS][AGX_NEQ], w[NS];
+#pragma unroll
+    for (int m = 0; m < NS; ++m) {
+      const long qq = q + (m - H) * s;
+      load5(b.state, qq, st[m]);
+      w[m] = b.wid[d][qq];
+    }
+    double al[4], au[4], l[AGX_NEQ], r[AGX_NEQ], J[AGX_NJ];
+    load_area(b, d, q, al);
+    load_area(b, d, q + s, au);
+    // the reference adds the upper neighbour's face first (face loop order i, i+1);
+    // the lower face of this cell is face `i`, visited before face `i + 1`
+    face_states_1d<RECON, LIM>(sp.kappa, st, w, H, l, r);
+    rusanov_flux_jacobian(g, r, al, false, J);
+#pragma unroll
+    for (int e = 0; e < AGX_NJ; ++e) D[e] -= J[e];
+    face_states_1d<RECON, LIM>(sp.kappa, st, w, H + 1, l, r);
+    rusanov_flux_jacobian(g, l, au, true, J);
+#pragma unroll
+    for (int e = 0; e < AGX_NJ; ++e) D[e] += J[e];
+  }
+#pragma unroll
+  for (int e = 0; e < AGX_NJ; ++e) b.am[(long)e * b.nplane + q] = D[e];
 }
 
 template <int RECON, int LIM, int FLUX>
@@ -1061,12 +1117,13 @@ __device__ __forceinline__ void uvwt(const BlockDev& b, const GasDev& g, long q,
   v[0] = b.state[1][q]; v[1] = b.state[2][q]; v[2] = b.state[3][q];
   v[3] = b.state[4][q] / (rho * g.R);
 }
-// viscous flux * |A| through the lower d-face of cell index qU (cells qL|qU)
-__device__ __forceinline__ void visc_face(const BlockDev& b, const GasDev& g,
-                                          int d, long qU, double* f, bool fourth = false) {
+// what the viscous flux and the thin-shear-layer Jacobian need at the lower d-face of
+// cell index qU (cells qL|qU): Green-Gauss gradients, face state and viscosity
+__device__ __forceinline__ void visc_face_terms(const BlockDev& b, const GasDev& g, int d,
+                                                long qU, bool fourth, double (*grad)[4],
+                                                double* sf, double& muf) {
   const long sd = b.stride(d);
   const long qL = qU - sd;
-  double grad[3][4];          // [derivative direction][u, v, w, T]
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -1119,7 +1176,6 @@ __device__ __forceinline__ void visc_face(const BlockDev& b, const GasDev& g,
   // FaceReconCentral reconstruction.hpp:315-328: coeffs = LagrangeCoeff(
   // {wU, wD}, 1, 0, 0) = {wD, wU} / (wU + wD) and the reference forms
   // coeffs[0] * varD + coeffs[1] * varU (the wider cell gets the larger weight)
-  double sf[AGX_NEQ], muf;
   if (fourth) {
     // FaceReconCentral4th reconstruction.hpp:335-379, LagrangeCoeff(w, 3, 1, 1);
     // state and viscosity of the four cells around the face (procBlock.cpp:1325-1346)
@@ -1148,6 +1204,13 @@ __device__ __forceinline__ void visc_face(const BlockDev& b, const GasDev& g,
     for (int e = 0; e < AGX_NEQ; ++e) sf[e] = cD * sU[e] + cU * sL[e];
     muf = cD * viscosity(g, vU[3]) + cU * viscosity(g, vL[3]);
   }
+}
+// viscous flux * |A| through the lower d-face of cell index qU (cells qL|qU)
+__device__ __forceinline__ void visc_face(const BlockDev& b, const GasDev& g,
+                                          int d, long qU, double* f, bool fourth = false) {
+  double grad[3][4];          // [derivative direction][u, v, w, T]
+  double sf[AGX_NEQ], muf;
+  visc_face_terms(b, g, d, qU, fourth, grad, sf, muf);
   double n[4];
   load_area(b, d, qU, n);
   const double mu = g.scaling * muf;
@@ -1168,6 +1231,52 @@ __device__ __forceinline__ void visc_face(const BlockDev& b, const GasDev& g,
   f[2] = tau[1] * n[3];
   f[3] = tau[2] * n[3];
   f[4] = (dot3(tau, sf + 1) + kk * tg) * n[3];
+}
+
+// Block-matrix solvers: thin-shear-layer part of the main diagonal of a cell (the
+// face Jacobian with left = false is added for its lower faces, the one with
+// left = true subtracted for its upper faces, procBlock.cpp:1417-1424, :1468-1475)
+// and the cell's velocity gradient, one sixth of each face gradient
+// (:1397, :1432), which the off-diagonal terms of the neighbours read.
+__global__ void __launch_bounds__(256)
+k_block_diag_visc(BlockDev b, GasDev g, SolverDev sp, int fourth) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  double D[AGX_NJ], vg[9];
+#pragma unroll
+  for (int e = 0; e < AGX_NJ; ++e) D[e] = b.am[(long)e * b.nplane + q];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) vg[e] = 0.0;
+  for (int d = 0; d < 3; ++d) {
+    const long s = b.stride(d);
+    for (int up = 0; up < 2; ++up) {
+      const long qU = q + (up ? s : 0), qL = qU - s;
+      double grad[3][4], sf[AGX_NEQ], muf, area[4], G[9], J[AGX_NJ];
+      visc_face_terms(b, g, d, qU, fourth != 0, grad, sf, muf);
+      load_area(b, d, qU, area);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          G[3 * r + c] = grad[r][c];
+          vg[3 * r + c] += (1.0 / 6.0) * grad[r][c];
+        }
+      const double v[3] = {b.cen[0][qU] - b.cen[0][qL], b.cen[1][qU] - b.cen[1][qL],
+                           b.cen[2][qU] - b.cen[2][qL]};
+      const double dist = dot3(v, area);     // ProjC2CDist procBlock.cpp:6316-6342
+      // this cell is the right cell of its lower face, the left cell of its upper face
+      tsl_jacobian(g, sf, muf, area, dist, up != 0, G, J);
+#pragma unroll
+      for (int e = 0; e < AGX_NJ; ++e) D[e] += up ? -J[e] : J[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < AGX_NJ; ++e) b.am[(long)e * b.nplane + q] = D[e];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) b.vg[(long)e * b.nplane + q] = vg[e];
 }
 
 __global__ void __launch_bounds__(256)
@@ -1768,8 +1877,15 @@ __device__ __forceinline__ void add_off_diag(const BlockDev& b, const GasDev& g,
       mu = viscosity(g, temperature(g, sn));
     }
     double sd[AGX_NEQ];
-    if (sp.roe_jacobian) load5(b.state, q, sd);
-    off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od, sp.roe_jacobian ? sd : nullptr);
+    if (sp.block) {
+      double vgn[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) vgn[e] = sp.viscous ? b.vg[(long)e * b.nplane + qn] : 0.0;
+      block_off_diagonal(g, sp.viscous != 0, sn, du, area, mu, dist, lower, vgn, od);
+    } else {
+      if (sp.roe_jacobian) load5(b.state, q, sd);
+      off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od, sp.roe_jacobian ? sd : nullptr);
+    }
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) acc[e] += sign * od[e];
   }
@@ -1778,7 +1894,7 @@ __device__ __forceinline__ void add_off_diag(const BlockDev& b, const GasDev& g,
 // linearSolver::AddDiagonalTerms :146-175, Invert :177-188,
 // InitializeMatrixUpdate :111-144
 __global__ void __launch_bounds__(256)
-k_implicit_begin(BlockDev b, GasDev g, SolverDev sp) {
+k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
@@ -1791,12 +1907,46 @@ k_implicit_begin(BlockDev b, GasDev g, SolverDev sp) {
   b.a[q] = a;
   b.ainv[q] = ainv;
   double x0[AGX_NEQ] = {0, 0, 0, 0, 0};
+  if (sp.block) {
+    // MultiplyOnDiagonal / AddOnDiagonal / Inverse, matMultiArray3d.hpp:96-111
+    double m[AGX_NJ];
+#pragma unroll
+    for (int e = 0; e < AGX_NJ; ++e) m[e] = b.am[(long)e * b.nplane + q];
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) m[AGX_NEQ * e + e] = m[AGX_NEQ * e + e] * sp.relax + dvt;
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) b.am[(long)(AGX_NEQ * e + e) * b.nplane + q] = m[AGX_NEQ * e + e];
+    if (!matrix_inverse5(m)) *err = 3;
+#pragma unroll
+    for (int e = 0; e < AGX_NJ; ++e) b.aminv[(long)e * b.nplane + q] = m[e];
+    if (sp.requires_init) {
+      double rb[AGX_NEQ];
+      rhs_b(b, g, sp, q, rb);
+      mat_vec5(m, rb, x0);
+    }
+    store5(b.x, q, x0);
+    return;
+  }
   if (sp.requires_init) {
     rhs_b(b, g, sp, q, x0);
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) x0[e] *= ainv;
   }
   store5(b.x, q, x0);
+}
+// aInv.ArrayMult (matMultiArray3d.hpp:141-160): scalar or block
+__device__ __forceinline__ void apply_ainv(const BlockDev& b, const SolverDev& sp, long q,
+                                           const double* v, double* out) {
+  if (sp.block) {
+    double m[AGX_NJ];
+#pragma unroll
+    for (int e = 0; e < AGX_NJ; ++e) m[e] = b.aminv[(long)e * b.nplane + q];
+    mat_vec5(m, v, out);
+  } else {
+    const double ainv = b.ainv[q];
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) out[e] = v[e] * ainv;
+  }
 }
 __global__ void k_zero5(Planes5 a, long n) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1815,22 +1965,22 @@ __global__ void k_copy5(Planes5 dst, Planes5 src, long n) {
 // LUSGS_Backward :385-428.  Cells of a plane are mutually independent
 // (HyperplaneReorder utility.cpp:377-398); planes are launched in order.
 template <bool FORWARD>
-__global__ void k_lusgs_plane(BlockDev b, GasDev g, SolverDev sp, int plane, int full) {
+__global__ void __launch_bounds__(256) k_lusgs_plane(BlockDev b, GasDev g, SolverDev sp, int plane, int full) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y * blockDim.y + threadIdx.y;
   if (j >= b.nj || k >= b.nk) return;
   const int i = plane - j - k;
   if (i < 0 || i >= b.ni) return;
   const long q = b.idx(i, j, k);
-  const double ainv = b.ainv[q];
-  double acc[AGX_NEQ] = {0, 0, 0, 0, 0};
+  double acc[AGX_NEQ] = {0, 0, 0, 0, 0}, out[AGX_NEQ];
   if (FORWARD) {
     add_off_diag(b, g, sp, b.x, i, j, k, q, true, 1.0, acc);
     if (full) add_off_diag(b, g, sp, b.x, i, j, k, q, false, -1.0, acc);
     double rb[AGX_NEQ];
     rhs_b(b, g, sp, q, rb);
 #pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) acc[e] = (rb[e] + acc[e]) * ainv;
+    for (int e = 0; e < AGX_NEQ; ++e) acc[e] = rb[e] + acc[e];
+    apply_ainv(b, sp, q, acc, out);
   } else {
     add_off_diag(b, g, sp, b.x, i, j, k, q, false, -1.0, acc);
     if (full) {
@@ -1838,15 +1988,17 @@ __global__ void k_lusgs_plane(BlockDev b, GasDev g, SolverDev sp, int plane, int
       double rb[AGX_NEQ];
       rhs_b(b, g, sp, q, rb);
 #pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e) acc[e] = (rb[e] + acc[e]) * ainv;
+      for (int e = 0; e < AGX_NEQ; ++e) acc[e] = rb[e] + acc[e];
+      apply_ainv(b, sp, q, acc, out);
     } else {
       double xo[AGX_NEQ];
       load5(b.x, q, xo);
+      apply_ainv(b, sp, q, acc, out);     // acc = -U
 #pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e) acc[e] = xo[e] + acc[e] * ainv;
+      for (int e = 0; e < AGX_NEQ; ++e) out[e] = xo[e] + out[e];
     }
   }
-  store5(b.x, q, acc);
+  store5(b.x, q, out);
 }
 
 }  // namespace agx
@@ -1865,10 +2017,11 @@ k_dplur(BlockDev b, GasDev g, SolverDev sp) {
   add_off_diag(b, g, sp, b.xold, i, j, k, q, true, 1.0, acc);
   add_off_diag(b, g, sp, b.xold, i, j, k, q, false, -1.0, acc);
   rhs_b(b, g, sp, q, rb);
-  const double ainv = b.ainv[q];
+  double out[AGX_NEQ];
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) acc[e] = (rb[e] + acc[e]) * ainv;
-  store5(b.x, q, acc);
+  for (int e = 0; e < AGX_NEQ; ++e) acc[e] = rb[e] + acc[e];
+  apply_ainv(b, sp, q, acc, out);
+  store5(b.x, q, out);
 }
 
 // linearSolver::AXmB :58-90 / Residual :92-109 as a pure reduction
@@ -1886,9 +2039,19 @@ k_matrix_resid(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
     add_off_diag(b, g, sp, b.x, i, j, k, q, false, -1.0, acc);
     rhs_b(b, g, sp, q, rb);
     load5(b.x, q, xc);
-    const double a = b.a[q];
+    double ax[AGX_NEQ];
+    if (sp.block) {
+      double m[AGX_NJ];
 #pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) r[e] = -(xc[e] * a - acc[e] - rb[e]);
+      for (int e = 0; e < AGX_NJ; ++e) m[e] = b.am[(long)e * b.nplane + q];
+      mat_vec5(m, xc, ax);
+    } else {
+      const double a = b.a[q];
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) ax[e] = xc[e] * a;
+    }
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) r[e] = -(ax[e] - acc[e] - rb[e]);
   }
   const long bid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   norm_block_reduce(r, 0, active, partials + bid);

@@ -276,7 +276,7 @@ class PhasedSolver(Solver):
         api.check(api.phase_residual(ctx, mm, cfl), "phase_residual")
         if self.case.deck.is_implicit():
             api.check(api.phase_implicit_begin(ctx), "phase_implicit_begin")
-            lusgs = cfg.matrix_solver == abi.SOLVER["lusgs"]
+            lusgs = cfg.matrix_solver in (abi.SOLVER["lusgs"], abi.SOLVER["blusgs"])
             for s in range(cfg.matrix_sweeps):
                 self._halo(abi.HALO_UPDATE)
                 api.check(api.phase_relax_forward(ctx, s), "relax_forward")

@@ -52,6 +52,7 @@ typedef struct {
   double *consn, *consnm1; /* consVarsN_, consVarsNm1_ [cells][NEQ] */
   double *x, *xold;      /* linearSolver x_ [cells_g][NEQ]      */
   double *a, *ainv;      /* linearSolver a_, aInv_ (scalar) [cells] */
+  double *am, *aminv;    /* block-matrix solvers: 5 x 5 per cell, row major (matMultiArray3d) */
   int nsurf;
   agx_bc_surface *surf;
   int nsurf_i, nsurf_j, nsurf_k;
@@ -1090,6 +1091,148 @@ static void face_states(const ora_ctx *c, const blk_t *b, int d, int i, int j,
 }
 
 /* procBlock::CalcInvFluxI/J/K procBlock.cpp:384-795 (scalar diagonal) */
+
+static double proj_c2c(const blk_t *b, int d, int i, int j, int k);
+/* ------------------------------------------------------------------------ */
+/* block-matrix solvers (blusgs / bdplur): 5 x 5 flow Jacobians, row major    */
+static int is_block(const ora_ctx *c) {    /* input::IsBlockMatrix input.cpp:713 */
+  return c->cfg.matrix_solver == AGX_SOLVER_BLUSGS || c->cfg.matrix_solver == AGX_SOLVER_BDPLUR;
+}
+static int is_lusgs(const ora_ctx *c) {    /* input.cpp:847 */
+  return c->cfg.matrix_solver == AGX_SOLVER_LUSGS || c->cfg.matrix_solver == AGX_SOLVER_BLUSGS;
+}
+#define NJ (NEQ * NEQ)
+/* fluxJacobian::InvFluxJacobian fluxJacobian.hpp:483-560, one species (mf = 1) */
+static void inv_flux_jacobian(const ora_ctx *c, const double *s, const double *area, double *J) {
+  const double *n = area;
+  const double velNorm = dot3(s + 1, n);
+  const double gamma = c->gamma, gm1 = gamma - 1.0;
+  const double phi = 0.5 * gm1 * dot3(s + 1, s + 1);
+  double u[NEQ];
+  prim_to_cons(c, s, u);
+  const double a1 = gamma * (u[4] / s[0]) - phi;     /* primitive::Energy */
+  const double a3 = gamma - 2.0;
+  for (int q = 0; q < NJ; ++q) J[q] = 0.0;
+#define JJ(r, cc) J[NEQ * (r) + (cc)]
+  JJ(0, 0) = velNorm * (1.0 - 1.0);
+  for (int q = 0; q < 3; ++q) {
+    JJ(0, 1 + q) = 1.0 * n[q];
+    JJ(1 + q, 0) = phi * n[q] - s[1 + q] * velNorm;
+  }
+  JJ(4, 0) = velNorm * (phi - a1);
+  for (int cc = 0; cc < 3; ++cc) {          /* columns of the momentum equations */
+    for (int r = 0; r < 3; ++r)
+      JJ(1 + r, 1 + cc) = r == cc ? velNorm - a3 * n[cc] * s[1 + cc]
+                                  : s[1 + r] * n[cc] - gm1 * s[1 + cc] * n[r];
+    JJ(4, 1 + cc) = a1 * n[cc] - gm1 * s[1 + cc] * velNorm;
+    JJ(1 + cc, 4) = gm1 * n[cc];
+  }
+  JJ(4, 4) = gamma * velNorm;
+  for (int q = 0; q < NJ; ++q) J[q] *= 0.5 * area[3];
+}
+/* fluxJacobian::RusanovFluxJacobian fluxJacobian.hpp:446-479, InvFaceSpectralRadius
+ * spectralRadius.hpp:67-80 */
+static void rusanov_flux_jacobian(const ora_ctx *c, const double *s, const double *area,
+                                  int positive, double *J) {
+  const double specRad = 0.5 * area[3] * (fabs(dot3(s + 1, area)) + sos(c, s));
+  inv_flux_jacobian(c, s, area, J);
+  for (int e = 0; e < NEQ; ++e) JJ(e, e) = positive ? JJ(e, e) + specRad : JJ(e, e) - specRad;
+}
+/* fluxJacobian::ApproxTSLJacobian fluxJacobian.hpp:660-758 with
+ * DelprimitiveDelConservative :613-656 and TauNormal utility.cpp:426-436; laminar,
+ * one species */
+static void tsl_jacobian(const ora_ctx *c, const double *s, double lamVisc, const double *area,
+                         double dist, int left, const double *vGrad, double *J) {
+  const double t = temperature(c, s);
+  const double mu = c->scaling * lamVisc, mut = c->scaling * 0.0;
+  const double *n = area;
+  const double velNorm = dot3(s + 1, n);
+  const double rho = s[0];
+  const double k = conductivity(c, t) * c->scaling;
+  const double kt = mut * c->cp / 0.9;
+  const double lambda = 0.0 - (2.0 / 3.0) * (mu + mut);
+  const double trace = vGrad[0] + vGrad[4] + vGrad[8];
+  double tauNorm[3];
+  for (int r = 0; r < 3; ++r) {
+    double mm = 0.0;
+    for (int q = 0; q < 3; ++q) mm += (vGrad[3 * r + q] + vGrad[3 * q + r]) * n[q];
+    tauNorm[r] = lambda * trace * n[r] + (mu + mut) * mm;
+  }
+  const double fac = left ? -1.0 : 1.0;
+  const double third = 1.0 / 3.0;
+  double T[NJ], P[NJ];
+  for (int q = 0; q < NJ; ++q) { T[q] = 0.0; P[q] = 0.0; }
+#define TT_(r, cc) T[NEQ * (r) + (cc)]
+#define PP_(r, cc) P[NEQ * (r) + (cc)]
+  TT_(0, 0) = 0.0;                                   /* DiffCoeff * (1 - mf) / ... */
+  TT_(4, 0) = -(k + kt) * t / ((mu + mut) * rho) + 0.0;
+  for (int cc = 0; cc < 3; ++cc) {
+    for (int r = 0; r < 3; ++r) TT_(1 + r, 1 + cc) = third * n[cc] * n[r] + (r == cc ? 1.0 : 0.0);
+    TT_(4, 1 + cc) = fac * 0.5 * dist / (mu + mut) * tauNorm[cc] + third * n[cc] * velNorm + s[1 + cc];
+  }
+  TT_(4, 4) = (k + kt) / ((mu + mut) * rho);
+  for (int q = 0; q < NJ; ++q) T[q] *= area[3] * (mu + mut) / dist;
+  const double gm1 = c->gamma - 1.0, invRho = 1.0 / rho;
+  PP_(0, 0) = 1.0;
+  for (int q = 0; q < 3; ++q) {
+    PP_(1 + q, 0) = -invRho * s[1 + q];
+    PP_(1 + q, 1 + q) = invRho;
+    PP_(4, 1 + q) = -gm1 * s[1 + q];
+  }
+  PP_(4, 0) = 0.5 * gm1 * dot3(s + 1, s + 1);
+  PP_(4, 4) = gm1;
+  for (int q = 0; q < NJ; ++q) J[q] = 0.0;
+  for (int cc = 0; cc < NEQ; ++cc)                   /* MatrixMultiply matrix.cpp:193-207 */
+    for (int rr = 0; rr < NEQ; ++rr)
+      for (int ii = 0; ii < NEQ; ++ii) JJ(rr, ii) += TT_(rr, cc) * PP_(cc, ii);
+}
+/* MatrixInverse matrix.cpp:57-103 (Gauss-Jordan, partial pivoting) */
+static int matrix_inverse(double *m, int size) {
+  double I[NJ];
+  for (int r = 0; r < size; ++r)
+    for (int q = 0; q < size; ++q) I[r * size + q] = r == q ? 1.0 : 0.0;
+  for (int cPivot = 0, r = 0; r < size; ++r, ++cPivot) {
+    double maxVal = 0.0;
+    int rPivot = 0;                                  /* FindMaxInColumn(mat, size, r, cPivot, size-1) */
+    for (int ii = cPivot; ii <= size - 1; ++ii)
+      if (fabs(m[ii * size + r]) > maxVal) { maxVal = fabs(m[ii * size + r]); rPivot = ii; }
+    if (r != rPivot)
+      for (int q = 0; q < size; ++q) {
+        double t = m[r * size + q]; m[r * size + q] = m[rPivot * size + q]; m[rPivot * size + q] = t;
+        t = I[r * size + q]; I[r * size + q] = I[rPivot * size + q]; I[rPivot * size + q] = t;
+      }
+    if (r != 0)
+      for (int ii = 0; ii < cPivot; ++ii) {
+        const double factor = m[r * size + ii] / m[ii * size + ii];
+        for (int q = 0; q < size; ++q) {
+          m[r * size + q] = m[r * size + q] - factor * m[ii * size + q];
+          I[r * size + q] = I[r * size + q] - factor * I[ii * size + q];
+        }
+      }
+    if (m[r * size + cPivot] == 0.0) return fail("Singular matrix in Gauss-Jordan elimination!");
+    const double normFactor = 1.0 / m[r * size + cPivot];
+    for (int q = cPivot; q < size; ++q) m[r * size + q] *= normFactor;
+    for (int q = 0; q < size; ++q) I[r * size + q] *= normFactor;
+  }
+  for (int cPivot = size - 2, r = size - 2; r >= 0; --r, --cPivot)
+    for (int ii = size - 1; ii > cPivot; --ii) {
+      const double factor = m[r * size + ii];
+      for (int q = 0; q < size; ++q) {
+        m[r * size + q] = m[r * size + q] - factor * m[ii * size + q];
+        I[r * size + q] = I[r * size + q] - factor * I[ii * size + q];
+      }
+    }
+  for (int q = 0; q < size * size; ++q) m[q] = I[q];
+  return 0;
+}
+/* ArrayMultiplication fluxJacobian.hpp:50-87 (block branch) */
+static void mat_vec(const double *m, const double *v, double *out) {
+  for (int rr = 0; rr < NEQ; ++rr) {
+    out[rr] = 0.0;
+    for (int cc = 0; cc < NEQ; ++cc) out[rr] += m[NEQ * rr + cc] * v[cc];
+  }
+}
+
 static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
   const int nn[3] = {b->ni, b->nj, b->nk};
   const int o[3] = {d == 0, d == 1, d == 2};
@@ -1106,13 +1249,24 @@ static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
           ausm_flux(c, fl, fr, area, flux);
         const int idx[3] = {i, j, k};
         if (idx[d] > 0) {
-          double *r = b->resid + NEQ * PI(b, i - o[0], j - o[1], k - o[2]);
+          const long pl = PI(b, i - o[0], j - o[1], k - o[2]);
+          double *r = b->resid + NEQ * pl;
           for (int e = 0; e < NEQ; ++e) r[e] += flux[e] * area[3];
+          if (implicit && is_block(c)) {             /* procBlock.cpp:452-457 */
+            double J[NJ];
+            rusanov_flux_jacobian(c, fl, area, 1, J);
+            for (int q = 0; q < NJ; ++q) b->am[NJ * pl + q] += J[q];
+          }
         }
         if (idx[d] < nn[d]) {
           const long p = PI(b, i, j, k);
           double *r = b->resid + NEQ * p;
           for (int e = 0; e < NEQ; ++e) r[e] -= flux[e] * area[3];
+          if (implicit && is_block(c)) {             /* procBlock.cpp:481-486 */
+            double J[NJ];
+            rusanov_flux_jacobian(c, fr, area, 0, J);
+            for (int q = 0; q < NJ; ++q) b->am[NJ * p + q] -= J[q];
+          }
           const double *au =
               b->fa[d] + 4 * FI(b, d, i + o[0], j + o[1], k + o[2]);
           const double sr = inv_cell_spec_rad(
@@ -1363,6 +1517,11 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
           const long p = PI(b, i - o[0], j - o[1], k - o[2]);
           for (int e = 0; e < NEQ; ++e) b->resid[NEQ * p + e] -= f[e] * area[3];
           for (int q = 0; q < 9; ++q) b->velgrad[9 * cL + q] += sixth * velGrad[q];
+          if (implicit && is_block(c)) {             /* procBlock.cpp:1417-1424 */
+            double J[NJ];
+            tsl_jacobian(c, st, mu, area, proj_c2c(b, d, i, j, k), 1, velGrad, J);
+            for (int q = 0; q < NJ; ++q) b->am[NJ * p + q] -= J[q];
+          }
         }
         if (idx[d] < nn[d]) {
           const long p = PI(b, i, j, k);
@@ -1374,6 +1533,11 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
                                                 au, b->vol[cU], b->visc[cU]);
           b->specrad[p] += vsr * viscCoeff;
           if (implicit) b->a[p] += 2.0 * vsr;
+          if (implicit && is_block(c)) {             /* procBlock.cpp:1468-1475 */
+            double J[NJ];
+            tsl_jacobian(c, st, mu, area, proj_c2c(b, d, i, j, k), 0, velGrad, J);
+            for (int q = 0; q < NJ; ++q) b->am[NJ * p + q] += J[q];
+          }
         }
       }
 }
@@ -1483,7 +1647,19 @@ static void rhs_b(const ora_ctx *c, const blk_t *b, int i, int j, int k,
  * spectralRadius.hpp:182-203, ConvectiveFluxUpdate inviscidFlux.hpp:544-562 */
 static void off_diagonal(const ora_ctx *c, const double *state, const double *diag,
                          const double *update, const double *fArea, double mu,
-                         double dist, int positive, double *out) {
+                         double dist, int positive, const double *vGrad, double *out) {
+  if (is_block(c)) {
+    /* RusanovBlockOffDiagonal fluxJacobian.cpp:164-194 */
+    double J[NJ];
+    rusanov_flux_jacobian(c, state, fArea, positive, J);
+    if (c->cfg.is_viscous) {
+      double V[NJ];
+      tsl_jacobian(c, state, mu, fArea, dist, positive, vGrad, V);
+      for (int q = 0; q < NJ; ++q) J[q] = positive ? J[q] - V[q] : J[q] + V[q];
+    }
+    mat_vec(J, update, out);
+    return;
+  }
   double su[NEQ], fo[NEQ], fn[NEQ];
   update_prim_with_cons(c, state, update, su);
   if (c->cfg.inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE) {
@@ -1531,7 +1707,7 @@ static void implicit_lower(const ora_ctx *c, const blk_t *b, int i, int j,
       double od[NEQ];
       off_diagonal(c, b->state + NEQ * q, b->state + NEQ * CI(b, i, j, k), x + NEQ * q,
                    b->fa[d] + 4 * FI(b, d, i, j, k),
-                   c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 1, od);
+                   c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 1, b->velgrad + 9 * q, od);
       for (int e = 0; e < NEQ; ++e) L[e] += od[e];
     }
   }
@@ -1549,7 +1725,7 @@ static void implicit_upper(const ora_ctx *c, const blk_t *b, int i, int j,
       double od[NEQ];
       off_diagonal(c, b->state + NEQ * q, b->state + NEQ * CI(b, i, j, k), x + NEQ * q,
                    b->fa[d] + 4 * FI(b, d, ii, jj, kk),
-                   c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 0, od);
+                   c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 0, b->velgrad + 9 * q, od);
       for (int e = 0; e < NEQ; ++e) U[e] += od[e];
     }
   }
@@ -1557,12 +1733,18 @@ static void implicit_upper(const ora_ctx *c, const blk_t *b, int i, int j,
 
 static int requires_init(const ora_ctx *c) {
   /* input::MatrixRequiresInitialization input.cpp:1120-1125 */
-  return c->cfg.matrix_solver == AGX_SOLVER_DPLUR || c->cfg.matrix_sweeps > 1;
+  return c->cfg.matrix_solver == AGX_SOLVER_DPLUR || c->cfg.matrix_solver == AGX_SOLVER_BDPLUR ||
+         c->cfg.matrix_sweeps > 1;
 }
 
 /* gridLevel::InvertDiagonal -> linearSolver::AddDiagonalTerms
  * linearSolver.cpp:146-175, Invert :177-188; InitializeMatrixUpdate :111-144 */
-static void implicit_begin(ora_ctx *c, blk_t *b) {
+/* aInv.ArrayMult(i, j, k, v) (matMultiArray3d.hpp:141-160): scalar or block */
+static void apply_ainv(const ora_ctx *c, const blk_t *b, long p, const double *v, double *out) {
+  if (is_block(c)) mat_vec(b->aminv + NJ * p, v, out);
+  else for (int e = 0; e < NEQ; ++e) out[e] = v[e] * b->ainv[p];
+}
+static int implicit_begin(ora_ctx *c, blk_t *b) {
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
@@ -1576,6 +1758,15 @@ static void implicit_begin(ora_ctx *c, blk_t *b) {
         b->a[p] *= c->cfg.matrix_relaxation;
         b->a[p] += diagVolTime;
         b->ainv[p] = 1.0 / b->a[p];
+        if (is_block(c)) {     /* MultiplyOnDiagonal / AddOnDiagonal / Inverse */
+          double *m = b->am + NJ * p, *mi = b->aminv + NJ * p;
+          for (int e = 0; e < NEQ; ++e) {
+            m[NEQ * e + e] *= c->cfg.matrix_relaxation;
+            m[NEQ * e + e] += diagVolTime;
+          }
+          memcpy(mi, m, sizeof(double) * NJ);
+          if (matrix_inverse(mi, NEQ)) return 1;
+        }
       }
   if (requires_init(c)) {
     for (int k = 0; k < b->nk; ++k)
@@ -1584,11 +1775,12 @@ static void implicit_begin(ora_ctx *c, blk_t *b) {
           const long p = PI(b, i, j, k), q = CI(b, i, j, k);
           double rb[NEQ];
           rhs_b(c, b, i, j, k, rb);
-          for (int e = 0; e < NEQ; ++e) b->x[NEQ * q + e] = rb[e] * b->ainv[p];
+          apply_ainv(c, b, p, rb, b->x + NEQ * q);
         }
   } else {
     memset(b->x, 0, sizeof(double) * NEQ * b->ncell_g);
   }
+  return 0;
 }
 
 /* lusgs::LUSGS_Forward linearSolver.cpp:341-383; hyperplane order
@@ -1608,8 +1800,9 @@ static void lusgs_forward(ora_ctx *c, blk_t *b, int sweep) {
         }
         rhs_b(c, b, i, j, k, rb);
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
-        for (int e = 0; e < NEQ; ++e)
-          b->x[NEQ * q + e] = (rb[e] + off[e]) * b->ainv[p];
+        double v[NEQ];
+        for (int e = 0; e < NEQ; ++e) v[e] = rb[e] + off[e];
+        apply_ainv(c, b, p, v, b->x + NEQ * q);
       }
 }
 /* lusgs::LUSGS_Backward linearSolver.cpp:385-428 */
@@ -1626,11 +1819,13 @@ static void lusgs_backward(ora_ctx *c, blk_t *b, int sweep) {
         if (sweep > 0 || requires_init(c)) {
           implicit_lower(c, b, i, j, k, b->x, L);
           rhs_b(c, b, i, j, k, rb);
-          for (int e = 0; e < NEQ; ++e)
-            b->x[NEQ * q + e] = (rb[e] + L[e] - U[e]) * b->ainv[p];
+          double v[NEQ];
+          for (int e = 0; e < NEQ; ++e) v[e] = rb[e] + L[e] - U[e];
+          apply_ainv(c, b, p, v, b->x + NEQ * q);
         } else {
-          for (int e = 0; e < NEQ; ++e)
-            b->x[NEQ * q + e] = b->x[NEQ * q + e] - U[e] * b->ainv[p];
+          double v[NEQ];
+          apply_ainv(c, b, p, U, v);
+          for (int e = 0; e < NEQ; ++e) b->x[NEQ * q + e] = b->x[NEQ * q + e] - v[e];
         }
       }
 }
@@ -1646,8 +1841,9 @@ static void dplur_sweep(ora_ctx *c, blk_t *b) {
         for (int e = 0; e < NEQ; ++e) off[e] -= U[e];
         rhs_b(c, b, i, j, k, rb);
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
-        for (int e = 0; e < NEQ; ++e)
-          b->x[NEQ * q + e] = (rb[e] + 0.0 + off[e]) * b->ainv[p];
+        double v[NEQ];
+        for (int e = 0; e < NEQ; ++e) v[e] = rb[e] + 0.0 + off[e];
+        apply_ainv(c, b, p, v, b->x + NEQ * q);
       }
 }
 /* linearSolver::AXmB :58-90 and Residual :92-109, squared and summed as in
@@ -1662,8 +1858,11 @@ static void matrix_residual(ora_ctx *c, blk_t *b, double *sumsq, long *size) {
         for (int e = 0; e < NEQ; ++e) off[e] -= U[e];
         rhs_b(c, b, i, j, k, rb);
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
+        double ax[NEQ];
+        if (is_block(c)) mat_vec(b->am + NJ * p, b->x + NEQ * q, ax);
+        else for (int e = 0; e < NEQ; ++e) ax[e] = b->x[NEQ * q + e] * b->a[p];
         for (int e = 0; e < NEQ; ++e) {
-          const double axmb = b->x[NEQ * q + e] * b->a[p] - off[e] - rb[e];
+          const double axmb = ax[e] - off[e] - rb[e];
           const double r = 0.0 - axmb;
           *sumsq += r * r;
         }
@@ -1689,7 +1888,7 @@ static void free_blk(blk_t *b) {
                      &b->center, &b->wid[0], &b->wid[1], &b->wid[2],
                      &b->wdist, &b->temp, &b->visc, &b->velgrad, &b->grad18, &b->resid,
                      &b->specrad, &b->dt, &b->consn, &b->consnm1, &b->x,
-                     &b->xold, &b->a, &b->ainv};
+                     &b->xold, &b->a, &b->ainv, &b->am, &b->aminv};
   for (size_t n = 0; n < sizeof ptrs / sizeof *ptrs; ++n) {
     free(*ptrs[n]);
     *ptrs[n] = NULL;
@@ -1708,6 +1907,22 @@ void ora_ctx_destroy(ora_ctx *c) {
   free(c);
 }
 int ora_ctx_set_stream(ora_ctx *c, void *s) { (void)c; (void)s; return 0; }
+
+/* test hook (tests/test_block_matrix.py): the Jacobians of the block-matrix solvers
+ * for one state / face.  which = 0: RusanovFluxJacobian, 1: ApproxTSLJacobian,
+ * 2: MatrixInverse of the 25 numbers in `vgrad_or_mat` */
+int ora_debug_jacobian(ora_ctx *c, int which, const double *state, const double *area,
+                       double mu, double dist, int flag, const double *vgrad_or_mat,
+                       double *out25) {
+  if (!c->have_cfg) return fail("config_set first");
+  if (which == 0) rusanov_flux_jacobian(c, state, area, flag, out25);
+  else if (which == 1) tsl_jacobian(c, state, mu, area, dist, flag, vgrad_or_mat, out25);
+  else {
+    memcpy(out25, vgrad_or_mat, sizeof(double) * NJ);
+    return matrix_inverse(out25, NEQ);
+  }
+  return 0;
+}
 
 int ora_config_set(ora_ctx *c, const agx_config *cfg) {
   if (cfg->n_eq != NEQ) return fail("oracle supports n_eq = 5 only");
@@ -1769,6 +1984,8 @@ int ora_block_create(ora_ctx *c, const agx_block_geom *g, int *id) {
   b->xold = dup_arr(NULL, NEQ * b->ncell_g);
   b->a = dup_arr(NULL, b->ncell);
   b->ainv = dup_arr(NULL, b->ncell);
+  b->am = dup_arr(NULL, NJ * b->ncell);
+  b->aminv = dup_arr(NULL, NJ * b->ncell);
   *id = c->nblk++;
   return 0;
 }
@@ -1923,18 +2140,19 @@ int ora_phase_explicit_update(ora_ctx *c, int mm, double *l2, agx_linf *linf) {
   return 0;
 }
 int ora_phase_implicit_begin(ora_ctx *c) {
-  for (int n = 0; n < c->nblk; ++n) implicit_begin(c, &c->blk[n]);
+  for (int n = 0; n < c->nblk; ++n)
+    if (implicit_begin(c, &c->blk[n])) return 1;
   return 0;
 }
 int ora_phase_relax_forward(ora_ctx *c, int sweep) {
   for (int n = 0; n < c->nblk; ++n) {
-    if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) lusgs_forward(c, &c->blk[n], sweep);
+    if (is_lusgs(c)) lusgs_forward(c, &c->blk[n], sweep);
     else dplur_sweep(c, &c->blk[n]);
   }
   return 0;
 }
 int ora_phase_relax_backward(ora_ctx *c, int sweep) {
-  if (c->cfg.matrix_solver != AGX_SOLVER_LUSGS) return 0;
+  if (!is_lusgs(c)) return 0;
   for (int n = 0; n < c->nblk; ++n) lusgs_backward(c, &c->blk[n], sweep);
   return 0;
 }
@@ -1955,6 +2173,7 @@ int ora_phase_implicit_update(ora_ctx *c, int mm, double *l2, agx_linf *linf) {
       memcpy(b->consnm1, b->consn, sizeof(double) * NEQ * b->ncell);
     /* gridLevel::ResetDiagonal gridLevel.cpp:408-412 */
     memset(b->a, 0, sizeof(double) * b->ncell);
+    memset(b->am, 0, sizeof(double) * NJ * b->ncell);
   }
   return 0;
 }
@@ -2091,11 +2310,11 @@ int ora_iterate(ora_ctx *c, int mm, double cfl, double *l2, agx_linf *linf,
   if (ora_phase_residual(c, mm, cfl)) return 1;
   *matrix_resid = 0.0;
   if (c->cfg.time_integration >= AGX_TIME_IMPLICIT_EULER) {
-    ora_phase_implicit_begin(c);
+    if (ora_phase_implicit_begin(c)) return 1;
     for (int s = 0; s < c->cfg.matrix_sweeps; ++s) {
       if (ora_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
       ora_phase_relax_forward(c, s);
-      if (c->cfg.matrix_solver == AGX_SOLVER_LUSGS) {
+      if (is_lusgs(c)) {
         if (ora_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
         ora_phase_relax_backward(c, s);
       }

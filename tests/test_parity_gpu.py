@@ -294,6 +294,23 @@ CASES = {
         n=(10, 9, 8), stretch=1.15, bcs=NONREFLECTING_WALL, equation_set="navierStokes",
         face_reconstruction="weno", limiter="none", inviscid_flux="ausm",
         time_integration="implicitEuler", matrix_solver="lusgs", cfl=10.0),
+    # block-matrix solvers (matMultiArray3d, RusanovBlockOffDiagonal, ApproxTSLJacobian):
+    # no single-species reference truth runs them; the oracle's Jacobians are pinned
+    # by tests/test_block_matrix.py, these are HIP-vs-oracle parity
+    "blusgs_muscl_roe": dict(
+        n=(11, 10, 9), stretch=1.15, skew=0.01, bcs=FARFIELD, time_integration="implicitEuler",
+        matrix_solver="blusgs", cfl=20.0),
+    "blusgs_weno_ausm_visc_2sweeps": dict(
+        n=(10, 9, 8), stretch=1.2, bcs=WALL_J, equation_set="navierStokes",
+        face_reconstruction="weno", limiter="none", inviscid_flux="ausm",
+        time_integration="implicitEuler", matrix_solver="blusgs", matrix_sweeps=2, cfl=10.0),
+    "bdplur_minmod_bdf2_dual": dict(
+        n=(10, 9, 8), stretch=1.1, bcs=FARFIELD, limiter="minmod", time_integration="bdf2",
+        nonlinear_iterations=2, dt=2.0e-5, dual_time_cfl=100.0, matrix_solver="bdplur",
+        matrix_sweeps=4, matrix_relaxation=1.2),
+    "bdplur_visc_iso_wall": dict(
+        n=(9, 9, 8), stretch=1.15, bcs=WALL_ISO, equation_set="navierStokes",
+        time_integration="implicitEuler", matrix_solver="bdplur", matrix_sweeps=3, cfl=5.0),
     "visc_central4th_weno_rk4": dict(
         n=(9, 10, 8), stretch=1.2, bcs=WALL_ISO, equation_set="navierStokes",
         face_reconstruction="weno", limiter="none",
@@ -305,6 +322,16 @@ CASES = {
 def test_synthetic_single_block_parity(agx, oracle, name):
     case = synthetic.single_block_case(**CASES[name])
     _close(*run_pair(agx, oracle, case, 3))
+
+
+@pytest.mark.gpu
+def test_stacked_blocks_parity_blusgs(agx, oracle):
+    """Block-matrix LU-SGS across interblock connections (inviscid: the ghost update
+    of the neighbour block enters RusanovBlockOffDiagonal)."""
+    case = synthetic.stacked_blocks_case(n=(8, 7, 5), nblocks=2, axis="j", stretch=1.1,
+                                         bcs=FARFIELD, time_integration="implicitEuler",
+                                         matrix_solver="blusgs", matrix_sweeps=2, cfl=10.0)
+    _close(*run_pair(agx, oracle, case, 2))
 
 
 @pytest.mark.parametrize("axis", ["i", "j", "k"])
