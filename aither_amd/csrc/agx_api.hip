@@ -335,6 +335,15 @@ Planes5 halo_planes(Block& b, int what) {
   Planes5 r;
   const bool z2 = halo_in_d2(b, what);
   r.stride = z2 ? 2 : 1;     // x of the D2 path sits in pair arrays (x0,x1) (x2,x3) (x4,-)
+  if (what == AGX_HALO_VELGRAD_A || what == AGX_HALO_VELGRAD_B) {
+    // velocityGrad_ (9 planes) in two halves of five slots; the fifth slot of the
+    // second half repeats component 8
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      const int comp = what == AGX_HALO_VELGRAD_A ? e : std::min(5 + e, 8);
+      r.p[e] = b.d.vg + (long)comp * b.d.nplane;
+    }
+    return r;
+  }
   for (int e = 0; e < AGX_NEQ; ++e)
     r.p[e] = what == AGX_HALO_STATE ? b.d.state[e]
              : (z2 ? b.d.d2.base + 2L * (PA_X + (e >> 1)) * b.d.d2.nd2 + (e & 1) : b.d.x[e]);
@@ -1068,10 +1077,6 @@ long mresid_wgs(const agx_ctx* c, const BlockDev& b) {
 int agx_setup_finalize(agx_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
   const int ng = c->cfg.n_ghost;
-  if (c->sp.implicit && c->sp.block && c->sp.viscous && !c->conns.empty())
-    return fail("block-matrix solvers with viscous terms are built for blocks without "
-                "connection surfaces: the velocity gradients of the cells across a "
-                "connection (SwapEddyViscAndGradients, gridLevel.cpp:343-368) are not exchanged");
   long max_parts = 1, max_halo = 1;
   long march_parts = 0;
   for (auto& blk : c->blocks) {
@@ -1605,6 +1610,9 @@ int agx_rccl_exchange_create(agx_ctx* c, const void* id128, int nranks, int rank
 // gridLevel::GetBoundaryConditions (state) / lusgs::Relax, dplur::Relax (update):
 // local connections, then the slabs of connections to other ranks
 int agx_halo_exchange(agx_ctx* c, int what) {
+  if (what < AGX_HALO_STATE || what > AGX_HALO_VELGRAD_B) return fail("bad halo selector %d", what);
+  if (what >= AGX_HALO_VELGRAD_A && !(c->sp.implicit && c->sp.block))
+    return fail("velocity gradients are kept (and exchanged) for the block-matrix solvers only");
   if (agx_halo_swap_local(c, what)) return 1;
   if (c->remote.empty()) return 0;
   if (!c->have_ex) return fail("connections to other ranks need an exchange (agx_set_exchange)");
@@ -1688,6 +1696,12 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
   *matrix_resid = 0.0;
   int rc;
   if (c->sp.implicit) {
+    // gridLevel::SwapEddyViscAndGradients gridLevel.cpp:386-388 (read by the
+    // off-diagonal terms of the block-matrix solvers only)
+    if (c->sp.block && c->sp.viscous && !c->conns.empty()) {
+      if (agx_halo_exchange(c, AGX_HALO_VELGRAD_A)) return 1;
+      if (agx_halo_exchange(c, AGX_HALO_VELGRAD_B)) return 1;
+    }
     // mgSolution::ImplicitUpdate :209-244; lusgs::Relax linearSolver.cpp:430-470;
     // dplur::Relax :509-535
     if (agx_phase_implicit_begin(c)) return 1;

@@ -26,10 +26,10 @@ class DistExchange:
     The production transport is the library's own RCCL one
     (agx_rccl_exchange_create)."""
 
-    def __init__(self, world):
+    def __init__(self, world, group=None):
         import torch
         import torch.distributed as dist
-        self.torch, self.dist, self.world = torch, dist, world
+        self.torch, self.dist, self.world, self.group = torch, dist, world, group
         self._swap = abi.SWAP_FN(self.swap)
         self._allgather = abi.ALLGATHER_FN(self.allgather)
         self.struct = abi.Exchange(None, self._swap, self._allgather, world, 1)
@@ -46,9 +46,9 @@ class DistExchange:
             if sl.count <= 0:
                 continue
             reqs.append(self.dist.isend(self._view(sl.send, sl.count, np.float64),
-                                        sl.peer, tag=sl.tag))
+                                        sl.peer, tag=sl.tag, group=self.group))
             reqs.append(self.dist.irecv(self._view(sl.recv, sl.count, np.float64),
-                                        sl.peer, tag=sl.tag))
+                                        sl.peer, tag=sl.tag, group=self.group))
         for r in reqs:
             r.wait()
         return 0
@@ -56,7 +56,7 @@ class DistExchange:
     def allgather(self, user, send, recv, nbytes, stream):
         mine = self._view(send, nbytes, np.uint8).clone()
         parts = [self.torch.empty(nbytes, dtype=self.torch.uint8) for _ in range(self.world)]
-        self.dist.all_gather(parts, mine)
+        self.dist.all_gather(parts, mine, group=self.group)
         out = self._view(recv, nbytes * self.world, np.uint8)
         for r, p in enumerate(parts):
             out[r * nbytes:(r + 1) * nbytes] = p
@@ -275,6 +275,10 @@ class PhasedSolver(Solver):
         api.check(api.phase_bc_edges(ctx), "phase_bc_edges")
         api.check(api.phase_residual(ctx, mm, cfl), "phase_residual")
         if self.case.deck.is_implicit():
+            block = cfg.matrix_solver in (abi.SOLVER["blusgs"], abi.SOLVER["bdplur"])
+            if block and cfg.is_viscous:      # gridLevel.cpp:386-388
+                self._halo(abi.HALO_VELGRAD_A)
+                self._halo(abi.HALO_VELGRAD_B)
             api.check(api.phase_implicit_begin(ctx), "phase_implicit_begin")
             lusgs = cfg.matrix_solver in (abi.SOLVER["lusgs"], abi.SOLVER["blusgs"])
             for s in range(cfg.matrix_sweeps):

@@ -41,6 +41,7 @@ from aither_amd.case import geometry as _geo
 from aither_amd.case import connections as _conn
 from aither_amd.solver import Solver, DistExchange
 
+GLOO_GROUP = None          # second process group of an N > 1 run (fallback transport)
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 BYTES_STAGE = 296          # explicit stage, nEq = 5
 BYTES_RESID_KERNEL = 216   # of which the residual kernel: state 5 + areas 12 +
@@ -220,6 +221,7 @@ def run_workload(args, workload, api, world, rank, local_rank):
     dims = tuple(int(v) for v in args.dims.split(",")) if args.dims else None
     case = rank_local_chain_case(rank, world, n, workload, dims)
     nonlin = case.deck.nonlinear_iterations
+    transport = "none"
     if world > 1 and args.backend == "nccl":
         # the library's own transport: RCCL on its stream (agx_rccl_exchange_create);
         # torch.distributed only carries the 128-byte id to the other ranks
@@ -228,9 +230,28 @@ def run_workload(args, workload, api, world, rank, local_rank):
             api.check(api.rccl_unique_id(idbuf), "rccl_unique_id")
         t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).cuda()
         dist.broadcast(t, src=0)
-        sol = Solver(api, case, device=local_rank, rank=rank,
-                     rccl=(bytes(t.cpu().numpy().tobytes()), world, rank))
+        sol, ok = None, 1
+        try:
+            sol = Solver(api, case, device=local_rank, rank=rank,
+                         rccl=(bytes(t.cpu().numpy().tobytes()), world, rank))
+            sol.store_time_n(0)                      # one iteration proves the transport
+            sol.iterate(0, case.deck.cfl(0))
+        except RuntimeError as exc:
+            ok = 0
+            print(f"[bench rank {rank}] in-library RCCL transport failed: {exc}",
+                  file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        transport = "rccl (in-library, agx_rccl_exchange_create)"
+        if int(flag.item()) == 0:
+            # every rank falls back together: host-staged slabs over the gloo group
+            if sol is not None:
+                sol.close()
+            sol = Solver(api, case, device=local_rank, rank=rank,
+                         exchange=DistExchange(world, group=GLOO_GROUP))
+            transport = "host buffers over gloo (fallback: RCCL transport failed)"
     elif world > 1:
+        transport = "host buffers over gloo (rehearsal)"
         # rehearsal: the same in-library path with host-staged slabs over gloo
         sol = Solver(api, case, device=local_rank, rank=rank, exchange=DistExchange(world))
     else:
@@ -282,7 +303,7 @@ def run_workload(args, workload, api, world, rank, local_rank):
         total_cells = 8 * (n // 2) ** 3
         cells_rank = total_cells // world
     return dict(workload=workload, n=n, elapsed=elapsed, groups=groups,
-                cells_rank=cells_rank, total_cells=total_cells)
+                cells_rank=cells_rank, total_cells=total_cells, transport=transport)
 
 
 def traffic_entry(workload, cells_rank):
@@ -369,8 +390,8 @@ def build_line(args, res, world):
                    "cells_per_gpu": cells_rank,
                    "halo": ("none" if world == 1 else
                             "RCCL grouped send/recv + all-gather of the norms on the "
-                            "library's stream" if args.backend == "nccl" else
-                            "host-staged slabs over gloo (rehearsal)")},
+                            "library's stream" if res.get("transport", "").startswith("rccl") else
+                            res.get("transport", "host-staged slabs over gloo"))},
         "roofline": roof,
     }
 
@@ -405,6 +426,8 @@ def main():
     if world > 1 and args.backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        global GLOO_GROUP
+        GLOO_GROUP = dist.new_group(backend="gloo")   # only used if the RCCL transport fails
     elif world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
 

@@ -78,7 +78,12 @@ enum { AGX_FIELD_STATE = 0,      /* state_      nEq, with ghosts           */
 };
 
 /* what a halo exchange carries (gridLevel.cpp:299-313, utility.cpp:400-423) */
-enum { AGX_HALO_STATE = 0, AGX_HALO_UPDATE = 1 };
+enum { AGX_HALO_STATE = 0, AGX_HALO_UPDATE = 1,
+       /* velocityGrad_ of the cells across connection surfaces, swapped after the
+        * residual (gridLevel.cpp:343-368, :386-388) and read by the off-diagonal
+        * terms of the block-matrix solvers with viscous terms; two halves of the
+        * nine components, each in slabs of the usual five slots per cell */
+       AGX_HALO_VELGRAD_A = 2, AGX_HALO_VELGRAD_B = 3 };
 
 /* ---- plain-old-data descriptors --------------------------------------- */
 

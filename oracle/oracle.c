@@ -1060,9 +1060,23 @@ static void build_side_map(const agx_connection *cc, int recv, const blk_t *br,
   *dst_out = dst; *src_out = src; *n_out = n;
 }
 
-static double *halo_array(blk_t *b, int what, int *ncomp) {
-  *ncomp = NEQ;
-  return what == AGX_HALO_STATE ? b->state : b->x;
+/* what a halo exchange moves per cell: `ncopy` doubles from base[stride * cell + off];
+ * a slab always carries NEQ slots per cell.  velocityGrad_ (9 per cell, swapped after
+ * the residual for the off-diagonal terms of the block-matrix solvers,
+ * gridLevel.cpp:343-368) goes in two halves. */
+typedef struct { double *base; int stride, off, ncopy; } halo_view;
+static halo_view halo_array(blk_t *b, int what) {
+  halo_view v = {b->x, NEQ, 0, NEQ};
+  if (what == AGX_HALO_STATE) v.base = b->state;
+  else if (what == AGX_HALO_VELGRAD_A) { v.base = b->velgrad; v.stride = 9; v.off = 0; v.ncopy = 5; }
+  else if (what == AGX_HALO_VELGRAD_B) { v.base = b->velgrad; v.stride = 9; v.off = 5; v.ncopy = 4; }
+  return v;
+}
+static void halo_get(const halo_view *v, long cell, double *slot) {
+  for (int e = 0; e < v->ncopy; ++e) slot[e] = v->base[(long)v->stride * cell + v->off + e];
+}
+static void halo_put(const halo_view *v, long cell, const double *slot) {
+  for (int e = 0; e < v->ncopy; ++e) v->base[(long)v->stride * cell + v->off + e] = slot[e];
 }
 
 /* ------------------------------------------------------------------------ */
@@ -2183,19 +2197,15 @@ int ora_halo_swap_local(ora_ctx *c, int what) {
     conn_t *k = &c->conn[n];
     if (!(k->c.rank[0] == c->rank && k->c.rank[1] == c->rank)) continue;
     blk_t *b0 = &c->blk[k->c.local_block[0]], *b1 = &c->blk[k->c.local_block[1]];
-    int nc;
-    double *a0 = halo_array(b0, what, &nc), *a1 = halo_array(b1, what, &nc);
+    const int nc = NEQ;
+    const halo_view a0 = halo_array(b0, what), a1 = halo_array(b1, what);
     /* both slices are taken before either insert (multiArray3d.hpp:810-821) */
-    double *s1 = (double *)malloc(sizeof(double) * nc * (k->n[0] > 0 ? k->n[0] : 1));
-    double *s0 = (double *)malloc(sizeof(double) * nc * (k->n[1] > 0 ? k->n[1] : 1));
-    for (long q = 0; q < k->n[0]; ++q)
-      memcpy(s1 + nc * q, a1 + nc * k->src[0][q], sizeof(double) * nc);
-    for (long q = 0; q < k->n[1]; ++q)
-      memcpy(s0 + nc * q, a0 + nc * k->src[1][q], sizeof(double) * nc);
-    for (long q = 0; q < k->n[0]; ++q)
-      memcpy(a0 + nc * k->dst[0][q], s1 + nc * q, sizeof(double) * nc);
-    for (long q = 0; q < k->n[1]; ++q)
-      memcpy(a1 + nc * k->dst[1][q], s0 + nc * q, sizeof(double) * nc);
+    double *s1 = (double *)calloc(nc * (k->n[0] > 0 ? k->n[0] : 1), sizeof(double));
+    double *s0 = (double *)calloc(nc * (k->n[1] > 0 ? k->n[1] : 1), sizeof(double));
+    for (long q = 0; q < k->n[0]; ++q) halo_get(&a1, k->src[0][q], s1 + nc * q);
+    for (long q = 0; q < k->n[1]; ++q) halo_get(&a0, k->src[1][q], s0 + nc * q);
+    for (long q = 0; q < k->n[0]; ++q) halo_put(&a0, k->dst[0][q], s1 + nc * q);
+    for (long q = 0; q < k->n[1]; ++q) halo_put(&a1, k->dst[1][q], s0 + nc * q);
     free(s0);
     free(s1);
   }
@@ -2221,10 +2231,8 @@ int ora_halo_pack(ora_ctx *c, int id, int what, double *buf) {
   const int s = my_side(c, k);
   if (s < 0) return fail("connection %d is not remote", id);
   blk_t *b = &c->blk[k->c.local_block[s]];
-  int nc;
-  double *a = halo_array(b, what, &nc);
-  for (long q = 0; q < k->n[1 - s]; ++q)
-    memcpy(buf + nc * q, a + nc * k->src[1 - s][q], sizeof(double) * nc);
+  const halo_view a = halo_array(b, what);
+  for (long q = 0; q < k->n[1 - s]; ++q) halo_get(&a, k->src[1 - s][q], buf + NEQ * q);
   return 0;
 }
 int ora_halo_unpack(ora_ctx *c, int id, int what, const double *buf) {
@@ -2233,10 +2241,8 @@ int ora_halo_unpack(ora_ctx *c, int id, int what, const double *buf) {
   const int s = my_side(c, k);
   if (s < 0) return fail("connection %d is not remote", id);
   blk_t *b = &c->blk[k->c.local_block[s]];
-  int nc;
-  double *a = halo_array(b, what, &nc);
-  for (long q = 0; q < k->n[s]; ++q)
-    memcpy(a + nc * k->dst[s][q], buf + nc * q, sizeof(double) * nc);
+  const halo_view a = halo_array(b, what);
+  for (long q = 0; q < k->n[s]; ++q) halo_put(&a, k->dst[s][q], buf + NEQ * q);
   return 0;
 }
 
@@ -2310,6 +2316,12 @@ int ora_iterate(ora_ctx *c, int mm, double cfl, double *l2, agx_linf *linf,
   if (ora_phase_residual(c, mm, cfl)) return 1;
   *matrix_resid = 0.0;
   if (c->cfg.time_integration >= AGX_TIME_IMPLICIT_EULER) {
+    /* gridLevel::SwapEddyViscAndGradients gridLevel.cpp:386-388 (read by the
+     * off-diagonal terms of the block-matrix solvers only) */
+    if (is_block(c) && c->cfg.is_viscous) {
+      if (ora_halo_exchange(c, AGX_HALO_VELGRAD_A)) return 1;
+      if (ora_halo_exchange(c, AGX_HALO_VELGRAD_B)) return 1;
+    }
     if (ora_phase_implicit_begin(c)) return 1;
     for (int s = 0; s < c->cfg.matrix_sweeps; ++s) {
       if (ora_halo_exchange(c, AGX_HALO_UPDATE)) return 1;

@@ -156,6 +156,11 @@ def test_matrix_inverse(oracle):
         m[rng.integers(5), :] *= 1e3          # force row exchanges
         inv = _jac(oracle, ctx, 2, STATE, AREA, extra=m.ravel())
         assert np.abs(inv.dot(m) - np.eye(5)).max() < 1e-10
+    # a diagonal Jacobian reduces the block solve to the scalar one: the inverse is the
+    # reciprocal of the scalar diagonal, bit for bit
+    for a in (3.7, 1.0e-3, 2.5e4):
+        inv = _jac(oracle, ctx, 2, STATE, AREA, extra=(a * np.eye(5)).ravel())
+        assert (inv == np.eye(5) * (1.0 / a)).all()
     oracle.ctx_destroy(ctx)
 
 

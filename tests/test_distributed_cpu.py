@@ -27,6 +27,11 @@ KW = {
                   matrix_sweeps=4, cfl=20.0),
     "lusgs": dict(face_reconstruction="weno", limiter="none",
                   time_integration="implicitEuler", cfl=10.0),
+    # viscous block-matrix solver: the velocity gradients cross the ranks as well
+    "blusgs_visc": dict(bcs={3: ("viscousWall", 2), 1: ("characteristic", 1),
+                             2: ("pressureOutlet", 3), 4: ("characteristic", 1)},
+                        equation_set="navierStokes", time_integration="implicitEuler",
+                        matrix_solver="blusgs", matrix_sweeps=2, cfl=10.0),
 }
 
 
@@ -99,7 +104,7 @@ def _run(world, kind, builder, steps=2, in_library=False):
 
 
 @pytest.mark.parametrize("world,kind", [(2, "rk4"), (2, "dplur"), (2, "lusgs"),
-                                        (3, "dplur")])
+                                        (3, "dplur"), (2, "blusgs_visc")])
 def test_phased_multiprocess_matches_single_process(oracle, world, kind):
     res = _run(world, kind, "stacked")
     case = synthetic.stacked_blocks_case((6, 5, 4), nblocks=world, axis="k",
@@ -118,7 +123,8 @@ def test_phased_multiprocess_matches_single_process(oracle, world, kind):
     ref.close()
 
 
-@pytest.mark.parametrize("world,kind", [(2, "rk4"), (2, "lusgs"), (3, "dplur")])
+@pytest.mark.parametrize("world,kind", [(2, "rk4"), (2, "lusgs"), (3, "dplur"),
+                                        (2, "blusgs_visc")])
 def test_iterate_with_exchange_matches_single_process(oracle, world, kind):
     """The in-library multi-rank path: iterate() itself packs, swaps (exchange
     table on gloo, host buffers) and unpacks the slabs of connections to other

@@ -334,6 +334,19 @@ def test_stacked_blocks_parity_blusgs(agx, oracle):
     _close(*run_pair(agx, oracle, case, 2))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,axis", [("blusgs", "i"), ("bdplur", "k")])
+def test_stacked_blocks_parity_block_viscous(agx, oracle, solver, axis):
+    """Viscous block-matrix solvers across connections: the thin-shear-layer part of
+    RusanovBlockOffDiagonal reads the velocity gradient of the cell across the
+    connection, exchanged after the residual (gridLevel.cpp:343-368, :386-388)."""
+    case = synthetic.stacked_blocks_case(n=(7, 8, 6), nblocks=2, axis=axis, stretch=1.15,
+                                         bcs=WALL_J, equation_set="navierStokes",
+                                         time_integration="implicitEuler",
+                                         matrix_solver=solver, matrix_sweeps=3, cfl=10.0)
+    _close(*run_pair(agx, oracle, case, 2))
+
+
 @pytest.mark.parametrize("axis", ["i", "j", "k"])
 def test_stacked_blocks_parity_dplur(agx, oracle, axis):
     """BASELINE config 4 in miniature: interblock connections + DPLUR."""
