@@ -17,7 +17,14 @@
 #include <stdarg.h>
 #include <float.h>
 
-#define NEQ 5
+/* equations per cell: 5 (euler / navierStokes) or 7 (rans: + k, omega).  One value
+ * for the whole library (test infrastructure, single-threaded): ora_config_set
+ * refuses a second live context with another count.  NEQM sizes local arrays, NF is
+ * the flow block of the block-matrix solvers. */
+static int g_neq = 5, g_live_cfg = 0;
+#define NEQ g_neq
+#define NEQM 7
+#define NF 5
 #define EPS 1.0e-30                /* include/macros.hpp.in:20 */
 #define WALL_DIST_NEG_TOL -1.0e-10 /* include/macros.hpp.in:23 */
 #define MAXBLK 64
@@ -36,7 +43,7 @@ static int fail(const char *fmt, ...) {
 typedef struct {
   int ni, nj, nk, ng, parent, gpos;
   int ci, cj, ck;        /* ghost-padded cell dims */
-  double *state;         /* state_        [cells_g][NEQ]        */
+  double *state;         /* state_        [cells_g][NEQM]        */
   double *fa[3];         /* fAreaI/J/K_   [faces_g][4]          */
   double *vol, *center;  /* vol_ [cells_g], center_ [cells_g][3] */
   double *wid[3];        /* cellWidthI/J/K_ [cells_g]           */
@@ -46,11 +53,11 @@ typedef struct {
   double *grad18;        /* cell gradients of the last residual [cells][18], blocks with
                             nonreflecting surfaces only (pressureGrad_, velocityGrad_ fed
                             to the LODI terms, procBlock.cpp:2503-2505) */
-  double *resid;         /* residual_ [cells][NEQ]              */
+  double *resid;         /* residual_ [cells][NEQM]              */
   double *specrad;       /* specRadius_ (flow part) [cells]     */
   double *dt;            /* dt_ [cells]                         */
-  double *consn, *consnm1; /* consVarsN_, consVarsNm1_ [cells][NEQ] */
-  double *x, *xold;      /* linearSolver x_ [cells_g][NEQ]      */
+  double *consn, *consnm1; /* consVarsN_, consVarsNm1_ [cells][NEQM] */
+  double *x, *xold;      /* linearSolver x_ [cells_g][NEQM]      */
   double *a, *ainv;      /* linearSolver a_, aInv_ (scalar) [cells] */
   double *am, *aminv;    /* block-matrix solvers: 5 x 5 per cell, row major (matMultiArray3d) */
   int nsurf;
@@ -172,7 +179,7 @@ static void update_prim_with_cons(const ora_ctx *c, const double *s,
                                   const double *du, double *out) {
   /* UpdatePrimWithCons primitive.hpp:206-231 (single species: the mass
    * fraction clip/renormalise is the identity for positive density) */
-  double u[NEQ];
+  double u[NEQM];
   prim_to_cons(c, s, u);
   for (int e = 0; e < NEQ; ++e) u[e] = u[e] + du[e];
   const double rho = u[0];
@@ -367,7 +374,7 @@ static void phys_flux(const ora_ctx *c, const double *s, const double *n,
 /* RoeFlux inviscidFlux.hpp:260-382, RoeAveragedState primitive.hpp:245-280 */
 static void roe_flux(const ora_ctx *c, const double *l, const double *r,
                      const double *n, double *flux) {
-  double roe[NEQ];
+  double roe[NEQM];
   const double denRatio = sqrt(r[0] / l[0]);
   roe[0] = l[0] * denRatio;
   roe[1] = (l[1] + denRatio * r[1]) / (1.0 + denRatio);
@@ -379,10 +386,10 @@ static void roe_flux(const ora_ctx *c, const double *l, const double *r,
   const double rhoR = roe[0];
   const double velNormR = dot3(roe + 1, n);
   const double mfR = roe[0] / roe[0];
-  double delta[NEQ];
+  double delta[NEQM];
   for (int e = 0; e < NEQ; ++e) delta[e] = r[e] - l[e];
   const double normVelDiff = dot3(delta + 1, n);
-  double diss[NEQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  double diss[NEQM] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const double entropyFix = 0.1;
   /* left moving acoustic wave */
   double waveSpeed = fabs(velNormR - aR);
@@ -424,7 +431,7 @@ static void roe_flux(const ora_ctx *c, const double *l, const double *r,
   diss[2] += wss * (roe[2] + aR * n[1]);
   diss[3] += wss * (roe[3] + aR * n[2]);
   diss[4] += wss * (hR + aR * velNormR);
-  double fl[NEQ], fr[NEQ];
+  double fl[NEQM], fr[NEQM];
   phys_flux(c, l, n, fl);
   phys_flux(c, r, n, fr);
   /* inviscidFlux::RoeFlux src/inviscidFlux.cpp:26-32 */
@@ -564,7 +571,7 @@ static void extrap_hold(const double *bnd, double factor, const double *in,
     for (int e = 0; e < NEQ; ++e) out[e] = bnd[e];
     return;
   }
-  double g[NEQ];
+  double g[NEQM];
   for (int e = 0; e < NEQ; ++e) g[e] = factor * bnd[e] - in[e];
   const double v = ghostRho * bndMf;
   g[0] = v > 0.0 ? v : 0.0;
@@ -576,7 +583,7 @@ static void extrap_hold(const double *bnd, double factor, const double *in,
 /* what the nonreflecting (LODI) branches of GetGhostState read besides the interior
  * state: dt and the state at time n of the adjacent cell, its pressure and velocity
  * gradients, Mach mean / maximum over the surface (procBlock.cpp:6233-6262) */
-typedef struct { double dt, sn[NEQ], pg[3], vg[9], avg_mach, max_mach; } nr_data;
+typedef struct { double dt, sn[NEQM], pg[3], vg[9], avg_mach, max_mach; } nr_data;
 static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
                           const double *areaUnit, int surf, const agx_bc_state *d,
                           int layer, double wallDist, const nr_data *nr, double *ghost);
@@ -617,7 +624,7 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
       ghost[0] = rho * (interior[0] / interior[0]);
     }
   } else if (bc == AGX_BC_CHARACTERISTIC) {
-    double fs[NEQ] = {d->density * 1.0, d->velocity[0], d->velocity[1],
+    double fs[NEQM] = {d->density * 1.0, d->velocity[0], d->velocity[1],
                       d->velocity[2], d->pressure};
     const double velIntNorm = dot3(interior + 1, n);
     const double SoSInt = sos(c, interior);
@@ -649,17 +656,17 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
     } else {
       return fail("characteristic BC: flow condition not recognized");
     }
-    double tmp[NEQ];
+    double tmp[NEQM];
     extrap_hold(ghost, 2.0, interior, tmp);
-    memcpy(ghost, tmp, sizeof tmp);
+    memcpy(ghost, tmp, sizeof(double) * NEQ);
     if (layer > 1) {
       extrap_hold(ghost, (double)layer, interior, tmp);
-      memcpy(ghost, tmp, sizeof tmp);
+      memcpy(ghost, tmp, sizeof(double) * NEQ);
     }
   } else if (bc == AGX_BC_INLET) {
     if (d->is_nonreflecting && !nr)
       return fail("nonreflecting inlet needs the state at time n (StoreOldSolution)");
-    double fs[NEQ] = {d->density * 1.0, d->velocity[0], d->velocity[1],
+    double fs[NEQM] = {d->density * 1.0, d->velocity[0], d->velocity[1],
                       d->velocity[2], d->pressure};
     const double velIntNorm = dot3(interior + 1, n);
     const double SoSInt = sos(c, interior);
@@ -692,12 +699,12 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
       ghost[2] = fs[2] - n[1] * dP / rhoSoSInt;
       ghost[3] = fs[3] - n[2] * dP / rhoSoSInt;
       }
-      double tmp[NEQ];
+      double tmp[NEQM];
       extrap_hold(ghost, 2.0, interior, tmp);
-      memcpy(ghost, tmp, sizeof tmp);
+      memcpy(ghost, tmp, sizeof(double) * NEQ);
       if (layer > 1) {
         extrap_hold(ghost, (double)layer, interior, tmp);
-        memcpy(ghost, tmp, sizeof tmp);
+        memcpy(ghost, tmp, sizeof(double) * NEQ);
       }
     }
   } else if (bc == AGX_BC_SUPERSONIC_INFLOW) {
@@ -734,12 +741,12 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
     ghost[2] = vbMag * d->direction[1];
     ghost[3] = vbMag * d->direction[2];
     ghost[4] = pb;
-    double tmp[NEQ];
+    double tmp[NEQM];
     extrap_hold(ghost, 2.0, interior, tmp);
-    memcpy(ghost, tmp, sizeof tmp);
+    memcpy(ghost, tmp, sizeof(double) * NEQ);
     if (layer > 1) {
       extrap_hold(ghost, (double)layer, interior, tmp);
-      memcpy(ghost, tmp, sizeof tmp);
+      memcpy(ghost, tmp, sizeof(double) * NEQ);
     }
   } else if (bc == AGX_BC_PRESSURE_OUTLET) {
     if (d->is_nonreflecting && !nr)
@@ -887,7 +894,7 @@ static int assign_ghost_faces(ora_ctx *c, blk_t *b, int viscous) {
           surf_ijk(d3, gCell, a1, a2, &gi, &gj, &gk);
           surf_ijk(d3, bnd, a1, a2, &fi, &fj, &fk);
           const double *area = b->fa[d3] + 4 * FI(b, d3, fi, fj, fk);
-          double g[NEQ];
+          double g[NEQM];
           int wi, wj, wk;                    /* procBlock.cpp:2813: aCell */
           surf_ijk(d3, aCell, a1, a2, &wi, &wj, &wk);
           if (is_nr) {
@@ -901,7 +908,7 @@ static int assign_ghost_faces(ora_ctx *c, blk_t *b, int viscous) {
                              &q->state, layer, b->wdist ? b->wdist[CI(b, wi, wj, wk)] : 0.0,
                              is_nr ? &nr : NULL, g))
             return 1;
-          memcpy(b->state + NEQ * CI(b, gi, gj, gk), g, sizeof g);
+          memcpy(b->state + NEQ * CI(b, gi, gj, gk), g, sizeof(double) * NEQ);
         }
       }
     }
@@ -961,26 +968,26 @@ static int assign_ghost_edges(ora_ctx *c, blk_t *b, int viscous) {
             PERM(d1, gCellD2, gCellD3);
             double *sG = b->state + NEQ * CI(b, idx[0], idx[1], idx[2]);
 #undef PERM
-            double g[NEQ];
+            double g[NEQM];
             if (bc2 == AGX_BC_SLIPWALL && bc3 != AGX_BC_SLIPWALL) {
               if (ghost_state(c, sP2, bc2, fArea2, surf2, &s2->state, layer2, 0.0, g))
                 return 1;
-              memcpy(sG, g, sizeof g);
+              memcpy(sG, g, sizeof(double) * NEQ);
             } else if (bc2 != AGX_BC_SLIPWALL && bc3 == AGX_BC_SLIPWALL) {
               if (ghost_state(c, sP3, bc3, fArea3, surf3, &s3->state, layer3, 0.0, g))
                 return 1;
-              memcpy(sG, g, sizeof g);
+              memcpy(sG, g, sizeof(double) * NEQ);
             } else if (!viscous || (bc2 == AGX_BC_VISCOUSWALL &&
                                     bc3 == AGX_BC_VISCOUSWALL)) {
               if (layer2 == layer3) {
                 for (int e = 0; e < NEQ; ++e) g[e] = 0.5 * (sP2[e] + sP3[e]);
-                memcpy(sG, g, sizeof g);
+                memcpy(sG, g, sizeof(double) * NEQ);
               } else if (layer2 > layer3) {
-                memcpy(g, sP3, sizeof g);
-                memcpy(sG, g, sizeof g);
+                memcpy(g, sP3, sizeof(double) * NEQ);
+                memcpy(sG, g, sizeof(double) * NEQ);
               } else {
-                memcpy(g, sP2, sizeof g);
-                memcpy(sG, g, sizeof g);
+                memcpy(g, sP2, sizeof(double) * NEQ);
+                memcpy(sG, g, sizeof(double) * NEQ);
               }
             }
           }
@@ -1115,19 +1122,19 @@ static int is_block(const ora_ctx *c) {    /* input::IsBlockMatrix input.cpp:713
 static int is_lusgs(const ora_ctx *c) {    /* input.cpp:847 */
   return c->cfg.matrix_solver == AGX_SOLVER_LUSGS || c->cfg.matrix_solver == AGX_SOLVER_BLUSGS;
 }
-#define NJ (NEQ * NEQ)
+#define NJ (NF * NF)
 /* fluxJacobian::InvFluxJacobian fluxJacobian.hpp:483-560, one species (mf = 1) */
 static void inv_flux_jacobian(const ora_ctx *c, const double *s, const double *area, double *J) {
   const double *n = area;
   const double velNorm = dot3(s + 1, n);
   const double gamma = c->gamma, gm1 = gamma - 1.0;
   const double phi = 0.5 * gm1 * dot3(s + 1, s + 1);
-  double u[NEQ];
+  double u[NEQM];
   prim_to_cons(c, s, u);
   const double a1 = gamma * (u[4] / s[0]) - phi;     /* primitive::Energy */
   const double a3 = gamma - 2.0;
   for (int q = 0; q < NJ; ++q) J[q] = 0.0;
-#define JJ(r, cc) J[NEQ * (r) + (cc)]
+#define JJ(r, cc) J[NF * (r) + (cc)]
   JJ(0, 0) = velNorm * (1.0 - 1.0);
   for (int q = 0; q < 3; ++q) {
     JJ(0, 1 + q) = 1.0 * n[q];
@@ -1150,7 +1157,7 @@ static void rusanov_flux_jacobian(const ora_ctx *c, const double *s, const doubl
                                   int positive, double *J) {
   const double specRad = 0.5 * area[3] * (fabs(dot3(s + 1, area)) + sos(c, s));
   inv_flux_jacobian(c, s, area, J);
-  for (int e = 0; e < NEQ; ++e) JJ(e, e) = positive ? JJ(e, e) + specRad : JJ(e, e) - specRad;
+  for (int e = 0; e < NF; ++e) JJ(e, e) = positive ? JJ(e, e) + specRad : JJ(e, e) - specRad;
 }
 /* fluxJacobian::ApproxTSLJacobian fluxJacobian.hpp:660-758 with
  * DelprimitiveDelConservative :613-656 and TauNormal utility.cpp:426-436; laminar,
@@ -1176,8 +1183,8 @@ static void tsl_jacobian(const ora_ctx *c, const double *s, double lamVisc, cons
   const double third = 1.0 / 3.0;
   double T[NJ], P[NJ];
   for (int q = 0; q < NJ; ++q) { T[q] = 0.0; P[q] = 0.0; }
-#define TT_(r, cc) T[NEQ * (r) + (cc)]
-#define PP_(r, cc) P[NEQ * (r) + (cc)]
+#define TT_(r, cc) T[NF * (r) + (cc)]
+#define PP_(r, cc) P[NF * (r) + (cc)]
   TT_(0, 0) = 0.0;                                   /* DiffCoeff * (1 - mf) / ... */
   TT_(4, 0) = -(k + kt) * t / ((mu + mut) * rho) + 0.0;
   for (int cc = 0; cc < 3; ++cc) {
@@ -1196,9 +1203,9 @@ static void tsl_jacobian(const ora_ctx *c, const double *s, double lamVisc, cons
   PP_(4, 0) = 0.5 * gm1 * dot3(s + 1, s + 1);
   PP_(4, 4) = gm1;
   for (int q = 0; q < NJ; ++q) J[q] = 0.0;
-  for (int cc = 0; cc < NEQ; ++cc)                   /* MatrixMultiply matrix.cpp:193-207 */
-    for (int rr = 0; rr < NEQ; ++rr)
-      for (int ii = 0; ii < NEQ; ++ii) JJ(rr, ii) += TT_(rr, cc) * PP_(cc, ii);
+  for (int cc = 0; cc < NF; ++cc)                   /* MatrixMultiply matrix.cpp:193-207 */
+    for (int rr = 0; rr < NF; ++rr)
+      for (int ii = 0; ii < NF; ++ii) JJ(rr, ii) += TT_(rr, cc) * PP_(cc, ii);
 }
 /* MatrixInverse matrix.cpp:57-103 (Gauss-Jordan, partial pivoting) */
 static int matrix_inverse(double *m, int size) {
@@ -1241,9 +1248,9 @@ static int matrix_inverse(double *m, int size) {
 }
 /* ArrayMultiplication fluxJacobian.hpp:50-87 (block branch) */
 static void mat_vec(const double *m, const double *v, double *out) {
-  for (int rr = 0; rr < NEQ; ++rr) {
+  for (int rr = 0; rr < NF; ++rr) {
     out[rr] = 0.0;
-    for (int cc = 0; cc < NEQ; ++cc) out[rr] += m[NEQ * rr + cc] * v[cc];
+    for (int cc = 0; cc < NF; ++cc) out[rr] += m[NF * rr + cc] * v[cc];
   }
 }
 
@@ -1254,7 +1261,7 @@ static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
   for (int k = 0; k < b->nk + o[2]; ++k)
     for (int j = 0; j < b->nj + o[1]; ++j)
       for (int i = 0; i < b->ni + o[0]; ++i) {
-        double fl[NEQ], fr[NEQ], flux[NEQ];
+        double fl[NEQM], fr[NEQM], flux[NEQM];
         face_states(c, b, d, i, j, k, fl, fr);
         const double *area = b->fa[d] + 4 * FI(b, d, i, j, k);
         if (c->cfg.inviscid_flux == AGX_FLUX_ROE)
@@ -1502,7 +1509,7 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
         calc_grads(b, d, i, j, k, velGrad, tGrad);
         const long cL = CI(b, i - o[0], j - o[1], k - o[2]);
         const long cU = CI(b, i, j, k);
-        double st[NEQ], mu;
+        double st[NEQM], mu;
         if (c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH) {
           /* FaceReconCentral4th reconstruction.hpp:335-379 with
            * LagrangeCoeff(cellWidth, 3, 1, 1); procBlock.cpp:1325-1346 */
@@ -1524,7 +1531,7 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
           mu = cf[0] * b->visc[cU] + cf[1] * b->visc[cL];
         }
         const double *area = b->fa[d] + 4 * FI(b, d, i, j, k);
-        double f[NEQ];
+        double f[NEQM];
         visc_flux(c, velGrad, tGrad, area, st, mu, f);
         const int idx[3] = {i, j, k};
         if (idx[d] > 0) {
@@ -1607,7 +1614,7 @@ static void update_block(ora_ctx *c, blk_t *b, int rr, double *l2,
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
         double *s = b->state + NEQ * q;
         const double *r = b->resid + NEQ * p;
-        double u[NEQ], ns[NEQ];
+        double u[NEQM], ns[NEQM];
         if (c->cfg.time_integration == AGX_TIME_EXPLICIT_EULER) {
           prim_to_cons(c, s, u);
           const double fac = b->dt[p] / b->vol[q];
@@ -1621,7 +1628,7 @@ static void update_block(ora_ctx *c, blk_t *b, int rr, double *l2,
         } else {
           update_prim_with_cons(c, s, b->x + NEQ * q, ns);
         }
-        memcpy(s, ns, sizeof ns);
+        memcpy(s, ns, sizeof(double) * NEQ);
         for (int e = 0; e < NEQ; ++e) l2[e] += r[e] * r[e];
         for (int e = 0; e < NEQ; ++e) {
           if (r[e] > linf->linf) {
@@ -1644,7 +1651,7 @@ static void rhs_b(const ora_ctx *c, const blk_t *b, int i, int j, int k,
   const double thetaInv = 1.0 / c->cfg.theta;
   const double coeffN =
       (b->vol[q] * (1.0 + c->cfg.zeta)) / (b->dt[p] * c->cfg.theta);
-  double u[NEQ];
+  double u[NEQM];
   prim_to_cons(c, b->state + NEQ * q, u);
   const int multi = c->cfg.time_integration == AGX_TIME_BDF2;
   const double coeffNm1 = (b->vol[q] * c->cfg.zeta) / (b->dt[p] * c->cfg.theta);
@@ -1674,7 +1681,7 @@ static void off_diagonal(const ora_ctx *c, const double *state, const double *di
     mat_vec(J, update, out);
     return;
   }
-  double su[NEQ], fo[NEQ], fn[NEQ];
+  double su[NEQM], fo[NEQM], fn[NEQM];
   update_prim_with_cons(c, state, update, su);
   if (c->cfg.inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE) {
     /* RoeOffDiagonal fluxJacobian.cpp:240-291 (inviscid: the viscous branch of the
@@ -1718,7 +1725,7 @@ static void implicit_lower(const ora_ctx *c, const blk_t *b, int i, int j,
     if (is_physical(b, ii, jj, kk) || bc_is_connection(b, i, j, k, 2 * d + 1)) {
       const double dist = proj_c2c(b, d, i, j, k);
       const long q = CI(b, ii, jj, kk);
-      double od[NEQ];
+      double od[NEQM];
       off_diagonal(c, b->state + NEQ * q, b->state + NEQ * CI(b, i, j, k), x + NEQ * q,
                    b->fa[d] + 4 * FI(b, d, i, j, k),
                    c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 1, b->velgrad + 9 * q, od);
@@ -1736,7 +1743,7 @@ static void implicit_upper(const ora_ctx *c, const blk_t *b, int i, int j,
         bc_is_connection(b, ii, jj, kk, 2 * d + 2)) {
       const double dist = proj_c2c(b, d, ii, jj, kk);
       const long q = CI(b, ii, jj, kk);
-      double od[NEQ];
+      double od[NEQM];
       off_diagonal(c, b->state + NEQ * q, b->state + NEQ * CI(b, i, j, k), x + NEQ * q,
                    b->fa[d] + 4 * FI(b, d, ii, jj, kk),
                    c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 0, b->velgrad + 9 * q, od);
@@ -1774,12 +1781,12 @@ static int implicit_begin(ora_ctx *c, blk_t *b) {
         b->ainv[p] = 1.0 / b->a[p];
         if (is_block(c)) {     /* MultiplyOnDiagonal / AddOnDiagonal / Inverse */
           double *m = b->am + NJ * p, *mi = b->aminv + NJ * p;
-          for (int e = 0; e < NEQ; ++e) {
-            m[NEQ * e + e] *= c->cfg.matrix_relaxation;
-            m[NEQ * e + e] += diagVolTime;
+          for (int e = 0; e < NF; ++e) {
+            m[NF * e + e] *= c->cfg.matrix_relaxation;
+            m[NF * e + e] += diagVolTime;
           }
           memcpy(mi, m, sizeof(double) * NJ);
-          if (matrix_inverse(mi, NEQ)) return 1;
+          if (matrix_inverse(mi, NF)) return 1;
         }
       }
   if (requires_init(c)) {
@@ -1787,7 +1794,7 @@ static int implicit_begin(ora_ctx *c, blk_t *b) {
       for (int j = 0; j < b->nj; ++j)
         for (int i = 0; i < b->ni; ++i) {
           const long p = PI(b, i, j, k), q = CI(b, i, j, k);
-          double rb[NEQ];
+          double rb[NEQM];
           rhs_b(c, b, i, j, k, rb);
           apply_ainv(c, b, p, rb, b->x + NEQ * q);
         }
@@ -1806,7 +1813,7 @@ static void lusgs_forward(ora_ctx *c, blk_t *b, int sweep) {
       for (int j = 0; j < b->nj; ++j) {
         const int i = pp - j - k;
         if (i < 0 || i >= b->ni) continue;
-        double off[NEQ], U[NEQ], rb[NEQ];
+        double off[NEQM], U[NEQM], rb[NEQM];
         implicit_lower(c, b, i, j, k, b->x, off);
         if (sweep > 0 || requires_init(c)) {
           implicit_upper(c, b, i, j, k, b->x, U);
@@ -1814,7 +1821,7 @@ static void lusgs_forward(ora_ctx *c, blk_t *b, int sweep) {
         }
         rhs_b(c, b, i, j, k, rb);
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
-        double v[NEQ];
+        double v[NEQM];
         for (int e = 0; e < NEQ; ++e) v[e] = rb[e] + off[e];
         apply_ainv(c, b, p, v, b->x + NEQ * q);
       }
@@ -1827,17 +1834,17 @@ static void lusgs_backward(ora_ctx *c, blk_t *b, int sweep) {
       for (int j = b->nj - 1; j >= 0; --j) {
         const int i = pp - j - k;
         if (i < 0 || i >= b->ni) continue;
-        double U[NEQ], L[NEQ], rb[NEQ];
+        double U[NEQM], L[NEQM], rb[NEQM];
         implicit_upper(c, b, i, j, k, b->x, U);
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
         if (sweep > 0 || requires_init(c)) {
           implicit_lower(c, b, i, j, k, b->x, L);
           rhs_b(c, b, i, j, k, rb);
-          double v[NEQ];
+          double v[NEQM];
           for (int e = 0; e < NEQ; ++e) v[e] = rb[e] + L[e] - U[e];
           apply_ainv(c, b, p, v, b->x + NEQ * q);
         } else {
-          double v[NEQ];
+          double v[NEQM];
           apply_ainv(c, b, p, U, v);
           for (int e = 0; e < NEQ; ++e) b->x[NEQ * q + e] = b->x[NEQ * q + e] - v[e];
         }
@@ -1849,13 +1856,13 @@ static void dplur_sweep(ora_ctx *c, blk_t *b) {
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
-        double off[NEQ], U[NEQ], rb[NEQ];
+        double off[NEQM], U[NEQM], rb[NEQM];
         implicit_lower(c, b, i, j, k, b->xold, off);
         implicit_upper(c, b, i, j, k, b->xold, U);
         for (int e = 0; e < NEQ; ++e) off[e] -= U[e];
         rhs_b(c, b, i, j, k, rb);
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
-        double v[NEQ];
+        double v[NEQM];
         for (int e = 0; e < NEQ; ++e) v[e] = rb[e] + 0.0 + off[e];
         apply_ainv(c, b, p, v, b->x + NEQ * q);
       }
@@ -1866,13 +1873,13 @@ static void matrix_residual(ora_ctx *c, blk_t *b, double *sumsq, long *size) {
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
-        double off[NEQ], U[NEQ], rb[NEQ];
+        double off[NEQM], U[NEQM], rb[NEQM];
         implicit_lower(c, b, i, j, k, b->x, off);
         implicit_upper(c, b, i, j, k, b->x, U);
         for (int e = 0; e < NEQ; ++e) off[e] -= U[e];
         rhs_b(c, b, i, j, k, rb);
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
-        double ax[NEQ];
+        double ax[NEQM];
         if (is_block(c)) mat_vec(b->am + NJ * p, b->x + NEQ * q, ax);
         else for (int e = 0; e < NEQ; ++e) ax[e] = b->x[NEQ * q + e] * b->a[p];
         for (int e = 0; e < NEQ; ++e) {
@@ -1911,6 +1918,7 @@ static void free_blk(blk_t *b) {
   b->surf = NULL;
 }
 void ora_ctx_destroy(ora_ctx *c) {
+  if (c && c->have_cfg) --g_live_cfg;
   if (!c) return;
   for (int n = 0; n < c->nblk; ++n) free_blk(&c->blk[n]);
   for (int n = 0; n < c->nconn; ++n)
@@ -1933,13 +1941,17 @@ int ora_debug_jacobian(ora_ctx *c, int which, const double *state, const double 
   else if (which == 1) tsl_jacobian(c, state, mu, area, dist, flag, vgrad_or_mat, out25);
   else {
     memcpy(out25, vgrad_or_mat, sizeof(double) * NJ);
-    return matrix_inverse(out25, NEQ);
+    return matrix_inverse(out25, NF);
   }
   return 0;
 }
 
 int ora_config_set(ora_ctx *c, const agx_config *cfg) {
-  if (cfg->n_eq != NEQ) return fail("oracle supports n_eq = 5 only");
+  if (cfg->n_eq != 5) return fail("oracle supports n_eq = 5 only");
+  if (g_live_cfg > 0 && !c->have_cfg && cfg->n_eq != g_neq)
+    return fail("oracle: one equation count per process at a time (%d live)", g_neq);
+  if (!c->have_cfg) ++g_live_cfg;
+  g_neq = cfg->n_eq;
   c->cfg = *cfg;
   c->have_cfg = 1;
   const agx_gas *g = &cfg->gas;
@@ -2304,7 +2316,7 @@ int ora_halo_exchange(ora_ctx *c, int what) {
  * norms are reduced over the ranks as main.cpp:254-264 does */
 int ora_iterate(ora_ctx *c, int mm, double cfl, double *l2, agx_linf *linf,
                 double *matrix_resid) {
-  double l2_in[NEQ];
+  double l2_in[NEQM];
   for (int e = 0; e < NEQ; ++e) l2_in[e] = l2[e];
   if (!c->have_ex)
     for (int n = 0; n < c->nconn; ++n)
