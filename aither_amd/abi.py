@@ -61,7 +61,8 @@ class BcState(C.Structure):
                 ("wall_heat_flux", C.c_double),
                 ("length_scale", C.c_double),
                 ("is_isothermal", C.c_int32), ("is_heat_flux", C.c_int32),
-                ("is_nonreflecting", C.c_int32), ("pad_", C.c_int32)]
+                ("is_nonreflecting", C.c_int32), ("pad_", C.c_int32),
+                ("turb_intensity", C.c_double), ("eddy_visc_ratio", C.c_double)]
 
 
 class BcSurface(C.Structure):

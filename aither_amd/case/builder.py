@@ -4,6 +4,7 @@ ghost geometry, connections, wall distance, initial state), as plain arrays in
 the reference's host layout ready to cross the C-ABI.
 """
 from dataclasses import dataclass, field
+import math
 import os
 import numpy as np
 
@@ -45,6 +46,9 @@ def nondim_state(deck, gas, st):
     r_ref, a_ref, t_ref, l_ref = gas.rho_ref, gas.a_ref, gas.t_ref, gas.l_ref
     out = abi.BcState()
     kind = st.kind
+    # DEFAULT_TURB_INTENSITY / DEFAULT_EDDY_VISC_RATIO inputStates.hpp:41-42
+    out.turb_intensity = st.get("turbulenceIntensity", 0.01)
+    out.eddy_visc_ratio = st.get("eddyViscosityRatio", 0.01)
     if kind in ("icState", "characteristic", "supersonicInflow", "inlet",
                 "subsonicInflow"):
         vel = st.get("velocity", [0.0, 0.0, 0.0])
@@ -90,8 +94,27 @@ def initial_primitive(deck, gas, block):
     if ic.get("file") is not None:
         raise NotImplementedError("cloud-file initial conditions")
     s = nondim_state(deck, gas, State("icState", ic.params))
-    return np.array([1.0 * s.density, s.velocity[0], s.velocity[1],
-                     s.velocity[2], s.pressure])
+    prim = [1.0 * s.density, s.velocity[0], s.velocity[1], s.velocity[2], s.pressure]
+    if deck.is_rans():
+        prim += list(farfield_turbulence(gas, prim, s.velocity, s.turb_intensity,
+                                         s.eddy_visc_ratio))
+    return np.array(prim)
+
+
+TURB_MIN = 1.0e-20      # turbModel::TkeMin / OmegaMin turbulence.hpp:72-73
+
+
+def farfield_turbulence(gas, prim, vel, intensity, ratio):
+    """primitive::ApplyFarfieldTurbBC (primitive.cpp:83-98): k and omega from a
+    turbulence intensity and an eddy-viscosity ratio, then LimitTurb."""
+    vmag = math.sqrt(vel[0] ** 2 + vel[1] ** 2 + vel[2] ** 2)
+    tke = 1.5 * (intensity * vmag) ** 2.0
+    t = prim[4] / (prim[0] * gas.gas_constant)              # idealGas::Temperature
+    mu_ref = gas.visc_c1 * gas.t_ref ** 1.5 / (gas.t_ref + gas.visc_s)
+    td = t * gas.t_ref
+    mu = gas.visc_c1 * td ** 1.5 / (td + gas.visc_s) / mu_ref   # sutherland::Viscosity
+    omega = prim[0] * tke / (ratio * mu)
+    return max(tke, TURB_MIN), max(omega, TURB_MIN)
 
 
 def _wall_distance(blocks):
@@ -166,7 +189,7 @@ def build_case(inp_path, grid_dir=None, deck=None, coords=None, ranks=None):
         g = _geo.BlockGeometry(x, ng)
         g.assign_ghost_geom(deck.bcs[b])
         prim = initial_primitive(deck, gas, b)
-        st = np.zeros((g.nk + 2 * ng, g.nj + 2 * ng, g.ni + 2 * ng, 5))
+        st = np.zeros((g.nk + 2 * ng, g.nj + 2 * ng, g.ni + 2 * ng, len(prim)))
         st[ng:ng + g.nk, ng:ng + g.nj, ng:ng + g.ni, :] = prim
         blocks.append(Block(g, deck.bcs[b], st, b, b, ranks[b], local_pos[b]))
         total += g.ni * g.nj * g.nk
@@ -183,7 +206,7 @@ def build_case(inp_path, grid_dir=None, deck=None, coords=None, ranks=None):
         # SwapWallDist (gridLevel.cpp:261-285)
         for c in conns:
             _swap_cell_field(c, blocks, lambda blk: blk.geom.wall_dist.a, ng)
-    return Case(deck, gas, blocks, conns, total)
+    return Case(deck, gas, blocks, conns, total, n_eq=7 if deck.is_rans() else 5)
 
 
 def _swap_cell_field(conn, blocks, getter, ng):
@@ -203,7 +226,7 @@ def _swap_cell_field(conn, blocks, getter, ng):
 def config_struct(case):
     d, g = case.deck, case.gas
     cfg = abi.Config()
-    cfg.n_eq = 5
+    cfg.n_eq = case.n_eq
     cfg.n_ghost = d.num_ghost_layers()
     if d.face_reconstruction == "constant":
         cfg.recon = abi.RECON["constant"]

@@ -120,7 +120,10 @@ class InputDeck:
                                          "bdf2")
 
     def is_viscous(self):
-        return self.equation_set == "navierStokes"
+        return self.equation_set in ("navierStokes", "rans")
+
+    def is_rans(self):
+        return self.equation_set == "rans"
 
     def is_multilevel_in_time(self):
         return self.time_integration == "bdf2"
@@ -186,8 +189,12 @@ class InputDeck:
         bad = []
         if len(self.fluids) != 1:
             bad.append("multi-species")
-        if self.equation_set not in ("euler", "navierStokes"):
+        if self.equation_set not in ("euler", "navierStokes", "rans"):
             bad.append(f"equationSet {self.equation_set}")
+        if self.equation_set == "rans" and self.turbulence_model != "sst2003":
+            bad.append(f"turbulenceModel {self.turbulence_model}")
+        if self.equation_set == "rans" and self.matrix_solver not in ("lusgs", "dplur"):
+            bad.append("rans with a block-matrix solver")
         if self.thermodynamic_model != "caloricallyPerfect":
             bad.append("thermallyPerfect")
         if self.multigrid_levels != 1:

@@ -83,7 +83,11 @@ enum { AGX_HALO_STATE = 0, AGX_HALO_UPDATE = 1,
         * residual (gridLevel.cpp:343-368, :386-388) and read by the off-diagonal
         * terms of the block-matrix solvers with viscous terms; two halves of the
         * nine components, each in slabs of the usual five slots per cell */
-       AGX_HALO_VELGRAD_A = 2, AGX_HALO_VELGRAD_B = 3 };
+       AGX_HALO_VELGRAD_A = 2, AGX_HALO_VELGRAD_B = 3,
+       /* rans: eddyViscosity_, f1_, f2_ of the cells across connection surfaces
+        * (SwapEddyViscAndGradients / SwapTurbVars, gridLevel.cpp:386-392); read by the
+        * off-diagonal terms.  Oracle only so far. */
+       AGX_HALO_TURB = 4 };
 
 /* ---- plain-old-data descriptors --------------------------------------- */
 
@@ -163,6 +167,9 @@ typedef struct agx_bc_state {
   double wall_heat_flux;     /* viscousWall constant heat flux             */
   double length_scale;       /* nonreflecting inlet / outlet               */
   int32_t is_isothermal, is_heat_flux, is_nonreflecting, pad_;
+  /* farfield turbulence of the state (ApplyFarfieldTurbBC, primitive.cpp:83-98):
+   * turbulenceIntensity and eddyViscosityRatio; read by rans runs only */
+  double turb_intensity, eddy_visc_ratio;
 } agx_bc_state;
 
 /* one boundarySurface (boundaryConditions.hpp:55-150): index ranges are the

@@ -25,6 +25,7 @@ static int g_neq = 5, g_live_cfg = 0;
 #define NEQ g_neq
 #define NEQM 7
 #define NF 5
+#define TURB_MIN 1.0e-20
 #define EPS 1.0e-30                /* include/macros.hpp.in:20 */
 #define WALL_DIST_NEG_TOL -1.0e-10 /* include/macros.hpp.in:23 */
 #define MAXBLK 64
@@ -60,6 +61,9 @@ typedef struct {
   double *x, *xold;      /* linearSolver x_ [cells_g][NEQM]      */
   double *a, *ainv;      /* linearSolver a_, aInv_ (scalar) [cells] */
   double *am, *aminv;    /* block-matrix solvers: 5 x 5 per cell, row major (matMultiArray3d) */
+  /* rans: turbulence part of specRadius_ / a_ / aInv_ (uncoupledScalar) [cells];
+   * (eddyViscosity_, f1_, f2_) interleaved [cells_g][3]; tkeGrad_, omegaGrad_ [cells][3] */
+  double *specrad_t, *a_t, *ainv_t, *turb3, *kgrad, *wgrad;
   int nsurf;
   agx_bc_surface *surf;
   int nsurf_i, nsurf_j, nsurf_k;
@@ -156,6 +160,7 @@ static void prim_to_cons(const ora_ctx *c, const double *s, double *u) {
   u[2] = rho * s[2];
   u[3] = rho * s[3];
   u[4] = rho * energy(c, s);
+  for (int e = NF; e < NEQ; ++e) u[e] = rho * s[e];     /* rho k, rho omega */
 }
 static void cons_to_prim(const ora_ctx *c, const double *u, double *s) {
   /* primitive::primitive(cons, phys) primitive.hpp:152-178;
@@ -174,6 +179,12 @@ static void cons_to_prim(const ora_ctx *c, const double *u, double *s) {
   const double cv = 0.0 + mf * (c->cfg.gas.gas_constant * c->cfg.gas.n);
   const double t = (spec - hf) / cv;
   s[4] = 0.0 + s[0] * c->cfg.gas.gas_constant * t;
+  /* turbulence variables, then primitive::LimitTurb primitive.cpp:100-106 with
+   * turbModel::TkeMin / OmegaMin = 1e-20 (turbulence.hpp:72-73) */
+  for (int e = NF; e < NEQ; ++e) {
+    s[e] = u[e] / rho;
+    if (!(s[e] > TURB_MIN)) s[e] = TURB_MIN;
+  }
 }
 static void update_prim_with_cons(const ora_ctx *c, const double *s,
                                   const double *du, double *out) {
@@ -369,6 +380,7 @@ static void phys_flux(const ora_ctx *c, const double *s, const double *n,
   f[2] = rho * velNorm * s[2] + s[4] * n[1];
   f[3] = rho * velNorm * s[3] + s[4] * n[2];
   f[4] = rho * velNorm * enthalpy(c, s);
+  for (int e = NF; e < NEQ; ++e) f[e] = rho * velNorm * s[e];
 }
 
 /* RoeFlux inviscidFlux.hpp:260-382, RoeAveragedState primitive.hpp:245-280 */
@@ -381,6 +393,7 @@ static void roe_flux(const ora_ctx *c, const double *l, const double *r,
   roe[2] = (l[2] + denRatio * r[2]) / (1.0 + denRatio);
   roe[3] = (l[3] + denRatio * r[3]) / (1.0 + denRatio);
   roe[4] = (l[4] + denRatio * r[4]) / (1.0 + denRatio);
+  for (int e = NF; e < NEQ; ++e) roe[e] = (l[e] + denRatio * r[e]) / (1.0 + denRatio);
   const double hR = enthalpy(c, roe);
   const double aR = sos(c, roe);
   const double rhoR = roe[0];
@@ -389,7 +402,7 @@ static void roe_flux(const ora_ctx *c, const double *l, const double *r,
   double delta[NEQM];
   for (int e = 0; e < NEQ; ++e) delta[e] = r[e] - l[e];
   const double normVelDiff = dot3(delta + 1, n);
-  double diss[NEQM] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  double diss[NEQM] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   const double entropyFix = 0.1;
   /* left moving acoustic wave */
   double waveSpeed = fabs(velNormR - aR);
@@ -402,6 +415,7 @@ static void roe_flux(const ora_ctx *c, const double *l, const double *r,
   diss[2] += wss * (roe[2] - aR * n[1]);
   diss[3] += wss * (roe[3] - aR * n[2]);
   diss[4] += wss * (hR - aR * velNormR);
+  for (int e = NF; e < NEQ; ++e) diss[e] += wss * roe[e];
   /* entropy wave */
   waveSpeed = fabs(velNormR);
   waveStrength = -delta[4] / (aR * aR);
@@ -431,6 +445,14 @@ static void roe_flux(const ora_ctx *c, const double *l, const double *r,
   diss[2] += wss * (roe[2] + aR * n[1]);
   diss[3] += wss * (roe[3] + aR * n[2]);
   diss[4] += wss * (hR + aR * velNormR);
+  for (int e = NF; e < NEQ; ++e) diss[e] += wss * roe[e];
+  /* turbulence waves, inviscidFlux.hpp:363-372 */
+  waveSpeed = fabs(velNormR);
+  for (int e = NF; e < NEQ; ++e) {
+    waveStrength = rhoR * delta[e] + roe[e] * delta[0] - delta[4] * roe[e] / (aR * aR);
+    wss = waveSpeed * waveStrength;
+    diss[e] += wss * 1.0;
+  }
   double fl[NEQM], fr[NEQM];
   phys_flux(c, l, n, fl);
   phys_flux(c, r, n, fr);
@@ -487,6 +509,7 @@ static void ausm_flux(const ora_ctx *c, const double *l, const double *r,
   f[2] = rhoL * vl * l[2] + pPlus * l[4] * n[1];
   f[3] = rhoL * vl * l[3] + pPlus * l[4] * n[2];
   f[4] = rhoL * vl * enthalpy(c, l);
+  for (int e = NF; e < NEQ; ++e) f[e] = rhoL * vl * l[e];
   const double vr = mMinusRBar * s;
   f[0] += r[0] * vr;
   const double rhoR = r[0];
@@ -494,6 +517,7 @@ static void ausm_flux(const ora_ctx *c, const double *l, const double *r,
   f[2] += rhoR * vr * r[2] + pMinus * r[4] * n[1];
   f[3] += rhoR * vr * r[3] + pMinus * r[4] * n[2];
   f[4] += rhoR * vr * enthalpy(c, r);
+  for (int e = NF; e < NEQ; ++e) f[e] += rhoR * vr * r[e];
 }
 
 /* InvCellSpectralRadius spectralRadius.hpp:44-64 */
@@ -506,18 +530,18 @@ static double inv_cell_spec_rad(const ora_ctx *c, const double *s,
   const double fMag = 0.5 * (al[3] + au[3]);
   return (fabs(dot3(s + 1, nv)) + sos(c, s)) * fMag;
 }
-/* ViscCellSpectralRadius spectralRadius.hpp:94-124 (laminar: mut = 0) */
-static double visc_term(const ora_ctx *c, double mu) {
-  return c->scaling * (mu / c->prandtl + 0.0 / 0.9);
+/* ViscCellSpectralRadius spectralRadius.hpp:94-124 */
+static double visc_term_t(const ora_ctx *c, double mu, double mut) {
+  return c->scaling * (mu / c->prandtl + mut / 0.9);
 }
 static double visc_cell_spec_rad(const ora_ctx *c, const double *s,
                                  const double *al, const double *au,
-                                 double vol, double mu) {
+                                 double vol, double mu, double mut) {
   const double fMag = 0.5 * (al[3] + au[3]);
   const double a = 4.0 / (3.0 * s[0]);
   const double b = c->gamma / s[0];
   const double maxTerm = a > b ? a : b;        /* max(a, b) */
-  return maxTerm * visc_term(c, mu) * fMag * fMag / vol;
+  return maxTerm * visc_term_t(c, mu, mut) * fMag * fMag / vol;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -584,19 +608,35 @@ static void extrap_hold(const double *bnd, double factor, const double *in,
  * state: dt and the state at time n of the adjacent cell, its pressure and velocity
  * gradients, Mach mean / maximum over the surface (procBlock.cpp:6233-6262) */
 typedef struct { double dt, sn[NEQM], pg[3], vg[9], avg_mach, max_mach; } nr_data;
+/* primitive::ApplyFarfieldTurbBC primitive.cpp:83-98 (k and omega from a turbulence
+ * intensity and an eddy-viscosity ratio, then LimitTurb) */
+static void apply_farfield_turb(const ora_ctx *c, double *s, const double *vel,
+                                double turbInten, double viscRatio) {
+  s[5] = 1.5 * pow(turbInten * mag3(vel), 2.0);
+  s[6] = s[0] * s[5] / (viscRatio * viscosity(c, temperature(c, s)));
+  for (int e = NF; e < NEQ; ++e)
+    if (!(s[e] > TURB_MIN)) s[e] = TURB_MIN;
+}
 static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
                           const double *areaUnit, int surf, const agx_bc_state *d,
-                          int layer, double wallDist, const nr_data *nr, double *ghost);
+                          int layer, double wallDist, double nuW, const nr_data *nr,
+                          double *ghost);
+/* nuW: kinematic viscosity of the wall-adjacent cell (rans viscous walls,
+ * procBlock.cpp:2814-2820) */
 static int ghost_state(const ora_ctx *c, const double *interior, int bc,
                        const double *areaVec, int surf,
-                       const agx_bc_state *d, int layer, double wallDist,
+                       const agx_bc_state *d, int layer, double wallDist, double nuW,
                        double *ghost) {
-  return ghost_state_nr(c, interior, bc, areaVec, surf, d, layer, wallDist, NULL, ghost);
+  return ghost_state_nr(c, interior, bc, areaVec, surf, d, layer, wallDist, nuW, NULL, ghost);
 }
 static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
                           const double *areaVec, int surf,
-                          const agx_bc_state *d, int layer, double wallDist,
+                          const agx_bc_state *d, int layer, double wallDist, double nuW,
                           const nr_data *nr, double *ghost) {
+  const int rans = NEQ > NF;
+  if (rans && bc != AGX_BC_SLIPWALL && bc != AGX_BC_VISCOUSWALL && bc != AGX_BC_CHARACTERISTIC)
+    return fail("rans: boundary type %d is not restated (slipWall, viscousWall, "
+                "characteristic, interblock, periodic are)", bc);
   for (int e = 0; e < NEQ; ++e) ghost[e] = interior[e];
   const int isLower = surf % 2 == 1;
   double n[3];
@@ -623,6 +663,14 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
       const double rho = ghost[4] / (R * tGhost);
       ghost[0] = rho * (interior[0] / interior[0]);
     }
+    if (rans) {
+      /* low-Re wall, ghostStates.cpp:261-279: k = 0 at the face, omega of Menter's
+       * wall value (WallBeta = beta1, turbulence.hpp:577) */
+      ghost[5] = -1.0 * interior[5];
+      const double wWall = c->scaling * c->scaling * 60.0 * nuW / (wallDist * wallDist * 0.075);
+      ghost[6] = 2.0 * wWall - interior[6];
+      if (layer > 1) ghost[6] = layer * ghost[6] - wWall;
+    }
   } else if (bc == AGX_BC_CHARACTERISTIC) {
     double fs[NEQM] = {d->density * 1.0, d->velocity[0], d->velocity[1],
                       d->velocity[2], d->pressure};
@@ -631,6 +679,7 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
     const double machInt = fabs(velIntNorm) / SoSInt;
     if (machInt >= 1.0 && velIntNorm < 0.0) {
       for (int e = 0; e < NEQ; ++e) ghost[e] = fs[e];
+      if (rans) apply_farfield_turb(c, ghost, fs + 1, d->turb_intensity, d->eddy_visc_ratio);
     } else if (machInt >= 1.0 && velIntNorm >= 0.0) {
       /* supersonic outflow: interior */
     } else if (machInt < 1.0 && velIntNorm < 0.0) {
@@ -644,6 +693,7 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
       ghost[1] = fs[1] - n[0] * dP / rhoSoSInt;
       ghost[2] = fs[2] - n[1] * dP / rhoSoSInt;
       ghost[3] = fs[3] - n[2] * dP / rhoSoSInt;
+      if (rans) apply_farfield_turb(c, ghost, fs + 1, d->turb_intensity, d->eddy_visc_ratio);
     } else if (machInt < 1.0 && velIntNorm >= 0.0) {
       const double rhoSoSInt = interior[0] * SoSInt;
       const double dP = interior[4] - fs[4];
@@ -662,6 +712,8 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
     if (layer > 1) {
       extrap_hold(ghost, (double)layer, interior, tmp);
       memcpy(ghost, tmp, sizeof(double) * NEQ);
+      /* (whatever the flow direction, ghostStates.cpp:381-387) */
+      if (rans) apply_farfield_turb(c, ghost, fs + 1, d->turb_intensity, d->eddy_visc_ratio);
     }
   } else if (bc == AGX_BC_INLET) {
     if (d->is_nonreflecting && !nr)
@@ -904,8 +956,12 @@ static int assign_ghost_faces(ora_ctx *c, blk_t *b, int viscous) {
             memcpy(nr.vg, b->grad18 + 18 * pa, sizeof nr.vg);
             memcpy(nr.pg, b->grad18 + 18 * pa + 15, sizeof nr.pg);
           }
+          /* rans viscous walls: nu of the wall-adjacent cell from the viscosity_ of the
+           * last UpdateAuxillaryVariables (procBlock.cpp:2814-2820) */
+          const long qa = CI(b, wi, wj, wk);
+          const double nuW = (NEQ > NF && viscous) ? b->visc[qa] / b->state[NEQ * qa] : 0.0;
           if (ghost_state_nr(c, b->state + NEQ * CI(b, i, j, k), bc, area, st,
-                             &q->state, layer, b->wdist ? b->wdist[CI(b, wi, wj, wk)] : 0.0,
+                             &q->state, layer, b->wdist ? b->wdist[qa] : 0.0, nuW,
                              is_nr ? &nr : NULL, g))
             return 1;
           memcpy(b->state + NEQ * CI(b, gi, gj, gk), g, sizeof(double) * NEQ);
@@ -970,11 +1026,11 @@ static int assign_ghost_edges(ora_ctx *c, blk_t *b, int viscous) {
 #undef PERM
             double g[NEQM];
             if (bc2 == AGX_BC_SLIPWALL && bc3 != AGX_BC_SLIPWALL) {
-              if (ghost_state(c, sP2, bc2, fArea2, surf2, &s2->state, layer2, 0.0, g))
+              if (ghost_state(c, sP2, bc2, fArea2, surf2, &s2->state, layer2, 0.0, 0.0, g))
                 return 1;
               memcpy(sG, g, sizeof(double) * NEQ);
             } else if (bc2 != AGX_BC_SLIPWALL && bc3 == AGX_BC_SLIPWALL) {
-              if (ghost_state(c, sP3, bc3, fArea3, surf3, &s3->state, layer3, 0.0, g))
+              if (ghost_state(c, sP3, bc3, fArea3, surf3, &s3->state, layer3, 0.0, 0.0, g))
                 return 1;
               memcpy(sG, g, sizeof(double) * NEQ);
             } else if (!viscous || (bc2 == AGX_BC_VISCOUSWALL &&
@@ -1077,6 +1133,7 @@ static halo_view halo_array(blk_t *b, int what) {
   if (what == AGX_HALO_STATE) v.base = b->state;
   else if (what == AGX_HALO_VELGRAD_A) { v.base = b->velgrad; v.stride = 9; v.off = 0; v.ncopy = 5; }
   else if (what == AGX_HALO_VELGRAD_B) { v.base = b->velgrad; v.stride = 9; v.off = 5; v.ncopy = 4; }
+  else if (what == AGX_HALO_TURB) { v.base = b->turb3; v.stride = 3; v.off = 0; v.ncopy = 3; }
   return v;
 }
 static void halo_get(const halo_view *v, long cell, double *slot) {
@@ -1294,6 +1351,17 @@ static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
               c, b->state + NEQ * CI(b, i, j, k), area, au);
           b->specrad[p] += sr;
           if (implicit) b->a[p] += sr;
+          if (NEQ > NF) {
+            /* turbModel::InviscidCellSpectralRadius turbulence.cpp:162-172 */
+            const double *sc = b->state + NEQ * CI(b, i, j, k);
+            double v[3] = {0.5 * (area[0] + au[0]), 0.5 * (area[1] + au[1]),
+                           0.5 * (area[2] + au[2])};
+            const double m = mag3(v);
+            const double nv[3] = {v[0] / m, v[1] / m, v[2] / m};
+            const double tsr = fabs(dot3(sc + 1, nv)) * (0.5 * (area[3] + au[3]));
+            b->specrad_t[p] += tsr;
+            if (implicit) b->a_t[p] += tsr;
+          }
         }
       }
 }
@@ -1318,7 +1386,7 @@ static void area_vec(const double *a, double *v) {
   v[0] = a[0] * a[3]; v[1] = a[1] * a[3]; v[2] = a[2] * a[3];
 }
 static void calc_grads(const blk_t *b, int d, int i, int j, int k,
-                       double *velGrad, double *tGrad) {
+                       double *velGrad, double *tGrad, double *kGrad, double *wGrad) {
   int o[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   const int *od = o[d];
   double al[3][3], au[3][3]; /* [direction][component] */
@@ -1351,9 +1419,11 @@ static void calc_grads(const blk_t *b, int d, int i, int j, int k,
   const double invVol = 1.0 / vol;
   /* values on the six faces of the alternate control volume, 4 fields:
    * u, v, w, T */
-  double vl[3][4], vu[3][4];
-  for (int f = 0; f < 4; ++f) {
-#define VAL(cell) (f < 3 ? b->state[NEQ * (cell) + 1 + f] : b->temp[(cell)])
+  /* (rans: + k, omega -- ScalarGradGG of the turbulence variables) */
+  const int nf = kGrad ? 6 : 4;
+  double vl[3][6], vu[3][6];
+  for (int f = 0; f < nf; ++f) {
+#define VAL(cell) (f < 3 ? b->state[NEQ * (cell) + 1 + f] : (f == 3 ? b->temp[(cell)] : b->state[NEQ * (cell) + f + 1]))
     vl[d][f] = VAL(cL);
     vu[d][f] = VAL(cU);
     for (int t = 0; t < 3; ++t) {
@@ -1372,12 +1442,14 @@ static void calc_grads(const blk_t *b, int d, int i, int j, int k,
   }
   /* tensor data_[3*r + c]: row r = derivative direction, c = velocity comp */
   for (int r = 0; r < 3; ++r) {
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < nf; ++f) {
       const double v =
           vu[0][f] * au[0][r] - vl[0][f] * al[0][r] + vu[1][f] * au[1][r] -
           vl[1][f] * al[1][r] + vu[2][f] * au[2][r] - vl[2][f] * al[2][r];
       if (f < 3) velGrad[3 * r + f] = v * invVol;
-      else tGrad[r] = v * invVol;
+      else if (f == 3) tGrad[r] = v * invVol;
+      else if (f == 4) kGrad[r] = v * invVol;
+      else wGrad[r] = v * invVol;
     }
   }
 }
@@ -1469,11 +1541,59 @@ static void central_coeffs(double wU, double wD, double *cf) {
 
 /* viscousFlux::CalcFlux / CalcWallFlux viscousFlux.cpp:58-211, TauNormal
  * utility.cpp:426-437 (laminar, single species) */
+/* k-omega SST 2003, turbulence.hpp:489-606 / turbulence.cpp:573-840 */
+#define SST_BETA_STAR 0.09
+#define SST_SIGMA_K1 0.85
+#define SST_SIGMA_K2 1.0
+#define SST_SIGMA_W1 0.5
+#define SST_SIGMA_W2 0.856
+#define SST_BETA1 0.075
+#define SST_BETA2 0.0828
+#define SST_GAMMA1 (5.0 / 9.0)
+#define SST_GAMMA2 0.44
+#define SST_A1 0.31
+#define SST_KPROD2DEST 10.0
+#define EPS_REF 1.0e-30                   /* macros.hpp.in:21 */
+static double sst_blend(double c1, double c2, double f1) { return f1 * c1 + (1.0 - f1) * c2; }
+static double sst_cdkw(const double *s, const double *kGrad, const double *wGrad) {
+  const double v = 2.0 * s[0] * SST_SIGMA_W2 / s[6] * dot3(kGrad, wGrad);
+  return v > 1.0e-10 ? v : 1.0e-10;       /* std::max(v, 1.0e-10) */
+}
+/* turbKWSst::EddyViscAndBlending turbulence.cpp:695-727 with Alpha1-3 :614-635,
+ * F1 / F2 :592-603 and EddyVisc :573-589 */
+static void sst_eddy_visc_blending(const ora_ctx *c, const double *s, const double *velGrad,
+                                   const double *kGrad, const double *wGrad, double mu,
+                                   double wallDist, double *mut, double *f1, double *f2) {
+  const double wd = wallDist + EPS_REF;
+  const double alpha1 = c->scaling * sqrt(s[5]) / (SST_BETA_STAR * s[6] * wd);
+  const double alpha2 = c->scaling * c->scaling * 500.0 * mu / (wd * wd * s[0] * s[6]);
+  const double cdkw = sst_cdkw(s, kGrad, wGrad);
+  const double alpha3 = 4.0 * s[0] * SST_SIGMA_W2 * s[5] / (cdkw * wd * wd);
+  const double m12 = alpha1 > alpha2 ? alpha1 : alpha2;
+  const double arg1 = m12 < alpha3 ? m12 : alpha3;
+  *f1 = tanh(pow(arg1, 4.0));
+  const double arg2 = 2.0 * alpha1 > alpha2 ? 2.0 * alpha1 : alpha2;
+  *f2 = tanh(arg2 * arg2);
+  double ss = 0.0;                        /* strainRate.DoubleDotTrans(strainRate) */
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) {
+      const double srq = 0.5 * (velGrad[3 * r + q] + velGrad[3 * q + r]);
+      const double sqr = 0.5 * (velGrad[3 * q + r] + velGrad[3 * r + q]);
+      ss += srq * sqr;
+    }
+  const double meanStrainRate = sqrt(2.0 * ss);
+  const double d1 = SST_A1 * s[6], d2 = c->scaling * meanStrainRate * *f2;
+  *mut = s[0] * SST_A1 * s[5] / (d1 > d2 ? d1 : d2);
+}
+
+/* viscousFlux::CalcFlux viscousFlux.cpp:58-135 (one species; turbVisc = 0 and no
+ * turbulence entries in laminar runs) */
 static void visc_flux(const ora_ctx *c, const double *velGrad,
                       const double *tGrad, const double *n, const double *s,
-                      double lamVisc, double *f) {
+                      double lamVisc, double turbVisc, double f1, const double *kGrad,
+                      const double *wGrad, double *f) {
   const double mu = c->scaling * lamVisc;
-  const double mut = c->scaling * 0.0;
+  const double mut = c->scaling * turbVisc;
   const double lambda = 0.0 - (2.0 / 3.0) * (mu + mut); /* sutherland::Lambda */
   const double trace = velGrad[0] + velGrad[4] + velGrad[8];
   double sym[9];
@@ -1493,6 +1613,12 @@ static void visc_flux(const ora_ctx *c, const double *velGrad,
   const double kk = conductivity(c, t) * c->scaling;
   const double kt = mut * c->cp / 0.9;
   f[4] = dot3(tau, s + 1) + (kk + kt) * dot3(tGrad, n) + 0.0;
+  if (NEQ > NF) {
+    const double tkeCoeff = sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1);
+    const double omgCoeff = sst_blend(SST_SIGMA_W1, SST_SIGMA_W2, f1);
+    f[5] = (mu + tkeCoeff * mut) * dot3(kGrad, n);
+    f[6] = (mu + omgCoeff * mut) * dot3(wGrad, n);
+  }
 }
 
 /* procBlock::CalcViscFluxI/J/K procBlock.cpp:1233-2135 (laminar, central) */
@@ -1505,8 +1631,9 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
   for (int k = 0; k < b->nk + o[2]; ++k)
     for (int j = 0; j < b->nj + o[1]; ++j)
       for (int i = 0; i < b->ni + o[0]; ++i) {
-        double velGrad[9], tGrad[3];
-        calc_grads(b, d, i, j, k, velGrad, tGrad);
+        const int rans = NEQ > NF;
+        double velGrad[9], tGrad[3], kGrad[3] = {0, 0, 0}, wGrad[3] = {0, 0, 0};
+        calc_grads(b, d, i, j, k, velGrad, tGrad, rans ? kGrad : NULL, rans ? wGrad : NULL);
         const long cL = CI(b, i - o[0], j - o[1], k - o[2]);
         const long cU = CI(b, i, j, k);
         double st[NEQM], mu;
@@ -1531,13 +1658,33 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
           mu = cf[0] * b->visc[cU] + cf[1] * b->visc[cL];
         }
         const double *area = b->fa[d] + 4 * FI(b, d, i, j, k);
-        double f[NEQM];
-        visc_flux(c, velGrad, tGrad, area, st, mu, f);
+        double f[NEQM], mut = 0.0, f1 = 0.0, f2 = 0.0;
+        if (rans) {
+          /* state.LimitTurb, wall distance at the face, eddy viscosity and blending
+           * (procBlock.cpp:1303-1355; the wall distance always by the two-cell rule) */
+          for (int e = NF; e < NEQ; ++e)
+            if (!(st[e] > TURB_MIN)) st[e] = TURB_MIN;
+          double cf[2];
+          central_coeffs(b->wid[d][cL], b->wid[d][cU], cf);
+          double wDist = cf[0] * b->wdist[cU] + cf[1] * b->wdist[cL];
+          if (wDist < 0.0 && wDist > -1.0e-10) wDist = 0.0;      /* WALL_DIST_NEG_TOL */
+          sst_eddy_visc_blending(c, st, velGrad, kGrad, wGrad, mu, wDist, &mut, &f1, &f2);
+        }
+        visc_flux(c, velGrad, tGrad, area, st, mu, mut, f1, kGrad, wGrad, f);
         const int idx[3] = {i, j, k};
         if (idx[d] > 0) {
           const long p = PI(b, i - o[0], j - o[1], k - o[2]);
           for (int e = 0; e < NEQ; ++e) b->resid[NEQ * p + e] -= f[e] * area[3];
           for (int q = 0; q < 9; ++q) b->velgrad[9 * cL + q] += sixth * velGrad[q];
+          if (rans) {                                  /* procBlock.cpp:1401-1409 */
+            b->turb3[3 * cL] += sixth * mut;
+            b->turb3[3 * cL + 1] += sixth * f1;
+            b->turb3[3 * cL + 2] += sixth * f2;
+            for (int q = 0; q < 3; ++q) {
+              b->kgrad[3 * p + q] += sixth * kGrad[q];
+              b->wgrad[3 * p + q] += sixth * wGrad[q];
+            }
+          }
           if (implicit && is_block(c)) {             /* procBlock.cpp:1417-1424 */
             double J[NJ];
             tsl_jacobian(c, st, mu, area, proj_c2c(b, d, i, j, k), 1, velGrad, J);
@@ -1548,18 +1695,83 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
           const long p = PI(b, i, j, k);
           for (int e = 0; e < NEQ; ++e) b->resid[NEQ * p + e] += f[e] * area[3];
           for (int q = 0; q < 9; ++q) b->velgrad[9 * cU + q] += sixth * velGrad[q];
+          if (rans) {                                  /* procBlock.cpp:1436-1444 */
+            b->turb3[3 * cU] += sixth * mut;
+            b->turb3[3 * cU + 1] += sixth * f1;
+            b->turb3[3 * cU + 2] += sixth * f2;
+            for (int q = 0; q < 3; ++q) {
+              b->kgrad[3 * p + q] += sixth * kGrad[q];
+              b->wgrad[3 * p + q] += sixth * wGrad[q];
+            }
+          }
           const double *au =
               b->fa[d] + 4 * FI(b, d, i + o[0], j + o[1], k + o[2]);
           const double vsr = visc_cell_spec_rad(c, b->state + NEQ * cU, area,
-                                                au, b->vol[cU], b->visc[cU]);
+                                                au, b->vol[cU], b->visc[cU], mut);
           b->specrad[p] += vsr * viscCoeff;
           if (implicit) b->a[p] += 2.0 * vsr;
+          if (rans) {
+            /* turbKWSst::ViscousCellSpectralRadius turbulence.cpp:797-815 with the
+             * face's mut and f1 (procBlock.cpp:1459-1466) */
+            const double fMag = 0.5 * (area[3] + au[3]);
+            const double tvsr = c->scaling * (fMag * fMag / b->vol[cU]) / b->state[NEQ * cU] *
+                                (b->visc[cU] + sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1) * mut);
+            b->specrad_t[p] += tvsr * viscCoeff;
+            if (implicit) b->a_t[p] += 2.0 * tvsr;
+          }
           if (implicit && is_block(c)) {             /* procBlock.cpp:1468-1475 */
             double J[NJ];
             tsl_jacobian(c, st, mu, area, proj_c2c(b, d, i, j, k), 0, velGrad, J);
             for (int q = 0; q < NJ; ++q) b->am[NJ * p + q] += J[q];
           }
         }
+      }
+}
+
+/* procBlock::CalcSrcTerms procBlock.cpp:5956-6027 with source::CalcTurbSrc
+ * source.cpp:60-92 and turbKWSst::CalcTurbSrc turbulence.cpp:637-690 (own physical
+ * cells only, so it may run before the turbulence variables are swapped) */
+static void calc_src_terms(ora_ctx *c, blk_t *b) {
+  const int implicit = c->cfg.time_integration >= AGX_TIME_IMPLICIT_EULER;
+  const double invScaling = 1.0 / c->scaling;
+  for (int k = 0; k < b->nk; ++k)
+    for (int j = 0; j < b->nj; ++j)
+      for (int i = 0; i < b->ni; ++i) {
+        const long p = PI(b, i, j, k), q = CI(b, i, j, k);
+        const double *s = b->state + NEQ * q;
+        const double *vg = b->velgrad + 9 * q;
+        const double *kg = b->kgrad + 3 * p, *wg = b->wgrad + 3 * p;
+        const double mut = b->turb3[3 * q], f1 = b->turb3[3 * q + 1];
+        const double vol = b->vol[q];
+        const double cdkw = sst_cdkw(s, kg, wg);
+        const double gamma = sst_blend(SST_GAMMA1, SST_GAMMA2, f1);
+        const double beta = sst_blend(SST_BETA1, SST_BETA2, f1);
+        const double tkeDest = invScaling * SST_BETA_STAR * (s[0] * s[5] * s[6] * 1.0);
+        const double omgDest = invScaling * beta * (s[0] * s[6] * s[6]);
+        /* BoussinesqReynoldsStress turbulence.cpp:57-69, DoubleDotTrans with velGrad */
+        const double lambda = 0.0 - (2.0 / 3.0) * mut;
+        const double trace = vg[0] + vg[4] + vg[8];
+        double ddot = 0.0;
+        for (int r = 0; r < 3; ++r)
+          for (int cc = 0; cc < 3; ++cc) {
+            const double id = r == cc ? 1.0 : 0.0;
+            const double tau = lambda * trace * id + mut * (vg[3 * r + cc] + vg[3 * cc + r]) -
+                               2.0 / 3.0 * s[0] * s[5] * id;
+            ddot += tau * vg[3 * cc + r];
+          }
+        double tkeProd = c->scaling * ddot;
+        if (SST_KPROD2DEST * tkeDest < tkeProd) tkeProd = SST_KPROD2DEST * tkeDest;
+        if (tkeProd < 0.0) tkeProd = 0.0;
+        double omgProd = gamma * s[0] / mut * tkeProd;
+        if (omgProd < 0.0) omgProd = 0.0;
+        const double omgCd = c->scaling * (1.0 - f1) * cdkw;
+        const double src5 = tkeProd - tkeDest, src6 = omgProd - omgDest + omgCd;
+        /* turbKWSst::SrcSpecRad turbulence.cpp:739-747 */
+        const double turbSpecRad = -2.0 * SST_BETA_STAR * s[6] * vol * invScaling;
+        b->specrad_t[p] -= turbSpecRad;
+        if (implicit) b->a_t[p] -= turbSpecRad;
+        b->resid[NEQ * p + 5] -= src5 * vol;
+        b->resid[NEQ * p + 6] -= src6 * vol;
       }
 }
 
@@ -1570,6 +1782,12 @@ static int calc_residual(ora_ctx *c, blk_t *b) {
   memset(b->resid, 0, sizeof(double) * NEQ * b->ncell);
   memset(b->specrad, 0, sizeof(double) * b->ncell);
   memset(b->velgrad, 0, sizeof(double) * 9 * b->ncell_g);
+  if (NEQ > NF) {                       /* ResetTurbVars, ResetGradients */
+    memset(b->specrad_t, 0, sizeof(double) * b->ncell);
+    memset(b->turb3, 0, sizeof(double) * 3 * b->ncell_g);
+    memset(b->kgrad, 0, sizeof(double) * 3 * b->ncell);
+    memset(b->wgrad, 0, sizeof(double) * 3 * b->ncell);
+  }
   for (int d = 0; d < 3; ++d) calc_inv_flux(c, b, d);
   if (c->cfg.is_viscous) {
     if (assign_ghost_faces(c, b, 1)) return 1;
@@ -1579,6 +1797,7 @@ static int calc_residual(ora_ctx *c, blk_t *b) {
   } else {
     update_aux(c, b);
   }
+  if (NEQ > NF) calc_src_terms(c, b);
   /* the cell gradients of this residual feed the nonreflecting ghost states of the
    * next ghost fill (pressureGrad_, velocityGrad_: procBlock.cpp:1397-1449 / :6143) */
   for (int sn = 0; sn < b->nsurf; ++sn)
@@ -1594,7 +1813,8 @@ static int calc_dt(ora_ctx *c, blk_t *b, double cfl) {
     } else if (cfl > 0.0) {
       int i = (int)(p % b->ni), j = (int)((p / b->ni) % b->nj),
           k = (int)(p / ((long)b->ni * b->nj));
-      const double sr = b->specrad[p] > 0.0 ? b->specrad[p] : 0.0; /* Max() */
+      double sr = b->specrad[p] > 0.0 ? b->specrad[p] : 0.0; /* uncoupledScalar::Max() */
+      if (NEQ > NF && b->specrad_t[p] > sr) sr = b->specrad_t[p];
       b->dt[p] = cfl * (b->vol[CI(b, i, j, k)] / sr);
     } else {
       return fail("Neither dt or cfl was specified!");
@@ -1668,7 +1888,8 @@ static void rhs_b(const ora_ctx *c, const blk_t *b, int i, int j, int k,
  * spectralRadius.hpp:182-203, ConvectiveFluxUpdate inviscidFlux.hpp:544-562 */
 static void off_diagonal(const ora_ctx *c, const double *state, const double *diag,
                          const double *update, const double *fArea, double mu,
-                         double dist, int positive, const double *vGrad, double *out) {
+                         double dist, int positive, const double *vGrad, double mut, double f1,
+                         double *out) {
   if (is_block(c)) {
     /* RusanovBlockOffDiagonal fluxJacobian.cpp:164-194 */
     double J[NJ];
@@ -1700,11 +1921,26 @@ static void off_diagonal(const ora_ctx *c, const double *state, const double *di
     const double a = 4.0 / (3.0 * state[0]);
     const double bq = c->gamma / state[0];
     const double maxTerm = a > bq ? a : bq;
-    sr += fArea[3] / dist * maxTerm * visc_term(c, mu);
+    sr += fArea[3] / dist * maxTerm * visc_term_t(c, mu, mut);
   }
-  for (int e = 0; e < NEQ; ++e) {
+  for (int e = 0; e < NF; ++e) {
     const double fc = 0.5 * fArea[3] * (fn[e] - fo[e]);
     out[e] = positive ? fc + update[e] * sr : fc - update[e] * sr;
+  }
+  if (NEQ > NF) {
+    /* turbulence entries: the flux change is dropped (fluxJacobian.cpp:145-148), the
+     * spectral radius is turbModel::FaceSpectralRadius turbulence.hpp:309-330 =
+     * InviscidFaceSpectralRadius (turbulence.cpp:174-186) + turbKWSst::
+     * ViscousFaceSpectralRadius (:817-831) */
+    const double velNorm = dot3(state + 1, fArea);
+    double tsr = positive ? 0.5 * fArea[3] * fabs(velNorm + fabs(velNorm))
+                          : 0.5 * fArea[3] * fabs(velNorm - fabs(velNorm));
+    tsr += c->scaling * (fArea[3] / dist) / state[0] *
+           (mu + sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1) * mut);
+    for (int e = NF; e < NEQ; ++e) {
+      const double fc = 0.0;
+      out[e] = positive ? fc + update[e] * tsr : fc - update[e] * tsr;
+    }
   }
 }
 /* procBlock::ProjC2CDist procBlock.cpp:6316-6342 */
@@ -1728,7 +1964,8 @@ static void implicit_lower(const ora_ctx *c, const blk_t *b, int i, int j,
       double od[NEQM];
       off_diagonal(c, b->state + NEQ * q, b->state + NEQ * CI(b, i, j, k), x + NEQ * q,
                    b->fa[d] + 4 * FI(b, d, i, j, k),
-                   c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 1, b->velgrad + 9 * q, od);
+                   c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 1, b->velgrad + 9 * q,
+                   NEQ > NF ? b->turb3[3 * q] : 0.0, NEQ > NF ? b->turb3[3 * q + 1] : 0.0, od);
       for (int e = 0; e < NEQ; ++e) L[e] += od[e];
     }
   }
@@ -1746,7 +1983,8 @@ static void implicit_upper(const ora_ctx *c, const blk_t *b, int i, int j,
       double od[NEQM];
       off_diagonal(c, b->state + NEQ * q, b->state + NEQ * CI(b, i, j, k), x + NEQ * q,
                    b->fa[d] + 4 * FI(b, d, ii, jj, kk),
-                   c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 0, b->velgrad + 9 * q, od);
+                   c->cfg.is_viscous ? b->visc[q] : 0.0, dist, 0, b->velgrad + 9 * q,
+                   NEQ > NF ? b->turb3[3 * q] : 0.0, NEQ > NF ? b->turb3[3 * q + 1] : 0.0, od);
       for (int e = 0; e < NEQ; ++e) U[e] += od[e];
     }
   }
@@ -1763,7 +2001,10 @@ static int requires_init(const ora_ctx *c) {
 /* aInv.ArrayMult(i, j, k, v) (matMultiArray3d.hpp:141-160): scalar or block */
 static void apply_ainv(const ora_ctx *c, const blk_t *b, long p, const double *v, double *out) {
   if (is_block(c)) mat_vec(b->aminv + NJ * p, v, out);
-  else for (int e = 0; e < NEQ; ++e) out[e] = v[e] * b->ainv[p];
+  else {
+    for (int e = 0; e < NF; ++e) out[e] = v[e] * b->ainv[p];
+    for (int e = NF; e < NEQ; ++e) out[e] = v[e] * b->ainv_t[p];   /* turbulence part */
+  }
 }
 static int implicit_begin(ora_ctx *c, blk_t *b) {
   for (int k = 0; k < b->nk; ++k)
@@ -1773,12 +2014,18 @@ static int implicit_begin(ora_ctx *c, blk_t *b) {
         double diagVolTime =
             (b->vol[q] * (1.0 + c->cfg.zeta)) / (b->dt[p] * c->cfg.theta);
         if (c->cfg.dual_time_cfl > 0.0) {
-          const double sr = b->specrad[p] > 0.0 ? b->specrad[p] : 0.0;
+          double sr = b->specrad[p] > 0.0 ? b->specrad[p] : 0.0;
+          if (NEQ > NF && b->specrad_t[p] > sr) sr = b->specrad_t[p];
           diagVolTime += sr / c->cfg.dual_time_cfl;
         }
         b->a[p] *= c->cfg.matrix_relaxation;
         b->a[p] += diagVolTime;
         b->ainv[p] = 1.0 / b->a[p];
+        if (NEQ > NF) {
+          b->a_t[p] *= c->cfg.matrix_relaxation;
+          b->a_t[p] += diagVolTime;
+          b->ainv_t[p] = 1.0 / b->a_t[p];
+        }
         if (is_block(c)) {     /* MultiplyOnDiagonal / AddOnDiagonal / Inverse */
           double *m = b->am + NJ * p, *mi = b->aminv + NJ * p;
           for (int e = 0; e < NF; ++e) {
@@ -1881,7 +2128,10 @@ static void matrix_residual(ora_ctx *c, blk_t *b, double *sumsq, long *size) {
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
         double ax[NEQM];
         if (is_block(c)) mat_vec(b->am + NJ * p, b->x + NEQ * q, ax);
-        else for (int e = 0; e < NEQ; ++e) ax[e] = b->x[NEQ * q + e] * b->a[p];
+        else {
+          for (int e = 0; e < NF; ++e) ax[e] = b->x[NEQ * q + e] * b->a[p];
+          for (int e = NF; e < NEQ; ++e) ax[e] = b->x[NEQ * q + e] * b->a_t[p];
+        }
         for (int e = 0; e < NEQ; ++e) {
           const double axmb = ax[e] - off[e] - rb[e];
           const double r = 0.0 - axmb;
@@ -1909,7 +2159,8 @@ static void free_blk(blk_t *b) {
                      &b->center, &b->wid[0], &b->wid[1], &b->wid[2],
                      &b->wdist, &b->temp, &b->visc, &b->velgrad, &b->grad18, &b->resid,
                      &b->specrad, &b->dt, &b->consn, &b->consnm1, &b->x,
-                     &b->xold, &b->a, &b->ainv, &b->am, &b->aminv};
+                     &b->xold, &b->a, &b->ainv, &b->am, &b->aminv, &b->specrad_t,
+                     &b->a_t, &b->ainv_t, &b->turb3, &b->kgrad, &b->wgrad};
   for (size_t n = 0; n < sizeof ptrs / sizeof *ptrs; ++n) {
     free(*ptrs[n]);
     *ptrs[n] = NULL;
@@ -1947,7 +2198,15 @@ int ora_debug_jacobian(ora_ctx *c, int which, const double *state, const double 
 }
 
 int ora_config_set(ora_ctx *c, const agx_config *cfg) {
-  if (cfg->n_eq != 5) return fail("oracle supports n_eq = 5 only");
+  if (cfg->n_eq != 5 && cfg->n_eq != 7) return fail("n_eq is 5, or 7 for rans");
+  if ((cfg->n_eq == 7) != (cfg->equation_set == AGX_EQN_RANS))
+    return fail("n_eq = 7 goes with equation_set rans and nothing else");
+  if (cfg->n_eq == 7 && cfg->turbulence_model != AGX_TURB_SST2003)
+    return fail("rans: only the sst2003 model is restated");
+  if (cfg->n_eq == 7 && (cfg->matrix_solver == AGX_SOLVER_BLUSGS ||
+                         cfg->matrix_solver == AGX_SOLVER_BDPLUR ||
+                         cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE))
+    return fail("rans: block-matrix solvers and approximateRoe are not restated");
   if (g_live_cfg > 0 && !c->have_cfg && cfg->n_eq != g_neq)
     return fail("oracle: one equation count per process at a time (%d live)", g_neq);
   if (!c->have_cfg) ++g_live_cfg;
@@ -2012,6 +2271,12 @@ int ora_block_create(ora_ctx *c, const agx_block_geom *g, int *id) {
   b->ainv = dup_arr(NULL, b->ncell);
   b->am = dup_arr(NULL, NJ * b->ncell);
   b->aminv = dup_arr(NULL, NJ * b->ncell);
+  b->specrad_t = dup_arr(NULL, b->ncell);
+  b->a_t = dup_arr(NULL, b->ncell);
+  b->ainv_t = dup_arr(NULL, b->ncell);
+  b->turb3 = dup_arr(NULL, 3 * b->ncell_g);
+  b->kgrad = dup_arr(NULL, 3 * b->ncell);
+  b->wgrad = dup_arr(NULL, 3 * b->ncell);
   *id = c->nblk++;
   return 0;
 }
@@ -2082,6 +2347,17 @@ int ora_state_upload(ora_ctx *c, int id, const double *s) {
   if (id < 0 || id >= c->nblk) return fail("bad block id");
   blk_t *b = &c->blk[id];
   memcpy(b->state, s, sizeof(double) * NEQ * b->ncell_g);
+  /* gridLevel::AuxillaryAndWidths main.cpp:169: temperature_ / viscosity_ of the
+   * physical cells before the first iteration (the rans wall ghost states read the
+   * viscosity_ of the LAST UpdateAuxillaryVariables, procBlock.cpp:2814) */
+  if (NEQ > NF)
+    for (int k = 0; k < b->nk; ++k)
+      for (int j = 0; j < b->nj; ++j)
+        for (int i = 0; i < b->ni; ++i) {
+          const long q = CI(b, i, j, k);
+          b->temp[q] = temperature(c, b->state + NEQ * q);
+          b->visc[q] = viscosity(c, b->temp[q]);
+        }
   return 0;
 }
 static double *field_ptr(blk_t *b, int field, long *n) {
@@ -2199,6 +2475,7 @@ int ora_phase_implicit_update(ora_ctx *c, int mm, double *l2, agx_linf *linf) {
       memcpy(b->consnm1, b->consn, sizeof(double) * NEQ * b->ncell);
     /* gridLevel::ResetDiagonal gridLevel.cpp:408-412 */
     memset(b->a, 0, sizeof(double) * b->ncell);
+    memset(b->a_t, 0, sizeof(double) * b->ncell);
     memset(b->am, 0, sizeof(double) * NJ * b->ncell);
   }
   return 0;
@@ -2334,6 +2611,8 @@ int ora_iterate(ora_ctx *c, int mm, double cfl, double *l2, agx_linf *linf,
       if (ora_halo_exchange(c, AGX_HALO_VELGRAD_A)) return 1;
       if (ora_halo_exchange(c, AGX_HALO_VELGRAD_B)) return 1;
     }
+    /* ... and of eddyViscosity_, f1_, f2_ (SwapTurbVars :389-392) */
+    if (NEQ > NF && ora_halo_exchange(c, AGX_HALO_TURB)) return 1;
     if (ora_phase_implicit_begin(c)) return 1;
     for (int s = 0; s < c->cfg.matrix_sweeps; ++s) {
       if (ora_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
