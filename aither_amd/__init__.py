@@ -7,4 +7,4 @@ residual + implicit-sweep hot path behind a C-ABI (include/aither_gfx950.h).
   aither_amd.case     case setup used by tests/bench (input deck, Plot3D
                       metrics, ghost geometry, connections)
 """
-from ._lib import load, LIB_PATH  # noqa: F401
+from ._lib import load, LIB_PATH, RANS_LIB_PATH  # noqa: F401

@@ -61,6 +61,7 @@ def make_deck(**kw):
     d.inviscid_flux = kw.get("inviscid_flux", "roe")
     d.viscous_face_reconstruction = kw.get("viscous_face_reconstruction", "central")
     d.inv_flux_jac = kw.get("inv_flux_jac", "rusanov")
+    d.turbulence_model = kw.get("turbulence_model", "none")
     d.matrix_solver = kw.get("matrix_solver", "lusgs")
     d.matrix_sweeps = kw.get("matrix_sweeps", 1)
     d.matrix_relaxation = kw.get("matrix_relaxation", 1.0)

@@ -335,6 +335,12 @@ Planes5 halo_planes(Block& b, int what) {
   Planes5 r;
   const bool z2 = halo_in_d2(b, what);
   r.stride = z2 ? 2 : 1;     // x of the D2 path sits in pair arrays (x0,x1) (x2,x3) (x4,-)
+#if AGX_NEQ == 7
+  if (what == AGX_HALO_TURB) {     // eddyViscosity_, f1_, f2_ in the first three slots
+    for (int e = 0; e < AGX_NEQ; ++e) r.p[e] = b.d.turb3[e < 3 ? e : 2];
+    return r;
+  }
+#endif
   if (what == AGX_HALO_VELGRAD_A || what == AGX_HALO_VELGRAD_B) {
     // velocityGrad_ (9 planes) in two halves of five slots; the fifth slot of the
     // second half repeats component 8
@@ -369,7 +375,7 @@ struct MarchPlan { dim3 grid; int kchunk; long nparts; };
 int g_march_tj = 6;   // cell rows per workgroup (512 threads)
 // the tile kernel addresses a plane with 32-bit byte offsets (SlabDev::ldb)
 bool tile_ok(const agx_ctx* c, const BlockDev& b) {
-  return c->use_tile && !c->use_gather && (double)b.nplane * 8.0 < 4294967296.0;
+  return AGX_FAST && c->use_tile && !c->use_gather && (double)b.nplane * 8.0 < 4294967296.0;
 }
 bool all_tile_ok(const agx_ctx* c) {
   for (const auto& blk : c->blocks)
@@ -413,12 +419,13 @@ template <int RECON, int LIM, int FLUX>
 void launch_inv_kernel(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
                        const MarchArgs& ma, const MarchPlan& mp) {
   const SlabDev sd = make_slab(b);
-  if (c->use_gather) {
+  if (c->use_gather || AGX_NEQ != 5) {   // (the 7-equation build runs the gather form)
     hipLaunchKernelGGL((k_inv_residual<RECON, LIM, FLUX>), cell_grid(b, CELL_BLOCK),
                        CELL_BLOCK, 0, c->stream, b, c->gas, c->sp, cfl);
     return;
   }
   const dim3 tb(64, g_march_tj + 2);
+#if AGX_FAST
   if (tile_ok(c, b)) {
     if (fuse && ma.store_consn)
       hipLaunchKernelGGL((k_residual_tile<RECON, LIM, FLUX, 2, 6>), mp.grid, tb, 0,
@@ -429,7 +436,9 @@ void launch_inv_kernel(agx_ctx* c, const BlockDev& b, double cfl, bool fuse,
     else
       hipLaunchKernelGGL((k_residual_tile<RECON, LIM, FLUX, 0, 6>), mp.grid, tb, 0,
                          c->stream, sd, c->gas, c->sp, cfl, ma);
-  } else {
+  } else
+#endif
+  {
     if (fuse)
       hipLaunchKernelGGL((k_residual_march<RECON, LIM, FLUX, true, 6>), mp.grid, tb, 0,
                          c->stream, sd, c->gas, c->sp, cfl, ma);
@@ -509,9 +518,10 @@ bool is_lusgs_solver(const agx_ctx* c) {   // input.cpp:847
 bool use_d2(const agx_ctx* c) {
   // (the Roe off-diagonal needs the state on both sides of a face: served by the
   // hyperplane-per-launch form on the SoA planes)
-  return c->sp.implicit && c->cfg.matrix_solver == AGX_SOLVER_LUSGS && c->lusgs_mode == 1 &&
+  return AGX_FAST && c->sp.implicit && c->cfg.matrix_solver == AGX_SOLVER_LUSGS && c->lusgs_mode == 1 &&
          c->cfg.inv_flux_jacobian == AGX_JACOBIAN_RUSANOV;
 }
+#if AGX_FAST
 // One LU-SGS half sweep over a block, one launch: a workgroup per k-plane marches
 // the plane's diagonals, the planes follow each other one step apart (k_lusgs_kp).
 template <bool FWD, bool FULL, bool CONN, int CH>
@@ -603,6 +613,10 @@ int lusgs_kp_variant(agx_ctx* c, Block& blk, int full) {
               : lusgs_kp_chunks<FWD, false, false>(c, blk);
 }
 
+#else
+constexpr int KP_MAX_DIAG = 1 << 30;
+#endif
+
 int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full) {
   const BlockDev& b = blk.d;
   if (!b.d2.base) {
@@ -619,7 +633,11 @@ int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full) {
     }
     return 0;
   }
+#if AGX_FAST
   return forward ? lusgs_kp_variant<true>(c, blk, full) : lusgs_kp_variant<false>(c, blk, full);
+#else
+  return fail("no diagonal-ordered sweep in this build");
+#endif
 }
 
 // consVarsN = cons(state) that agx_store_time_n deferred (see there)
@@ -711,6 +729,7 @@ int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       const BlockDev& b = c->blocks[n].d;
       const int last = mm == c->cfg.nonlinear_iterations - 1;
+#if AGX_FAST
       if (mode == 2 && b.d2.base) {
         const dim3 tg((b.ni + TT - 1) / TT, (b.nj + TT - 1) / TT, b.nk);
         hipLaunchKernelGGL(k_update_d2, tg, dim3(256), 0, c->stream, b, c->gas, c->sp, last,
@@ -718,6 +737,7 @@ int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
         if (reduce_norms(c, n, (long)tg.x * tg.y * tg.z)) return 1;
         continue;
       }
+#endif
       const dim3 grid = cell_grid(b, CELL_BLOCK);
       hipLaunchKernelGGL(k_update, grid, CELL_BLOCK, 0, c->stream, b, c->gas,
                          c->sp, mode, mode == 1 ? alpha[mm & 3] : 1.0, last,
@@ -855,19 +875,30 @@ int agx_ctx_set_stream(agx_ctx* c, void* s) {
 
 int agx_config_set(agx_ctx* c, const agx_config* cfg) {
   if (cfg->n_eq != AGX_NEQ)
-    return fail("n_eq = %d: this build covers the 5-equation single-species "
-                "set", cfg->n_eq);
+    return fail("n_eq = %d: this library is built for %d equations (5: euler / "
+                "navierStokes, libaither_gfx950.so; 7: rans, libaither_gfx950_rans.so)",
+                cfg->n_eq, AGX_NEQ);
   if (cfg->n_ghost < 1 || cfg->n_ghost > 3) return fail("n_ghost out of range");
   // Never substitute: a scheme this build does not implement is an error here,
   // not a different scheme silently (mgSolution.hpp:112-115 must mean the same).
+#if AGX_NEQ == 7
+  if (cfg->equation_set != AGX_EQN_RANS || !cfg->is_viscous)
+    return fail("the 7-equation library serves equation_set rans (viscous) only");
+  if (cfg->turbulence_model != AGX_TURB_SST2003)
+    return fail("turbulence_model %d: only sst2003 is built", cfg->turbulence_model);
+  if (cfg->matrix_solver == AGX_SOLVER_BLUSGS || cfg->matrix_solver == AGX_SOLVER_BDPLUR ||
+      cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE)
+    return fail("rans: block-matrix solvers and approximateRoe are not built");
+#else
   if (cfg->equation_set != AGX_EQN_EULER && cfg->equation_set != AGX_EQN_NAVIER_STOKES)
-    return fail("equation_set %d: this build covers euler and navierStokes (RANS and its "
-                "turbulence closures are not built)", cfg->equation_set);
+    return fail("equation_set %d: this library covers euler and navierStokes "
+                "(rans: libaither_gfx950_rans.so)", cfg->equation_set);
   if ((cfg->equation_set == AGX_EQN_NAVIER_STOKES) != (cfg->is_viscous != 0))
     return fail("equation_set %d contradicts is_viscous %d", cfg->equation_set, cfg->is_viscous);
   if (cfg->turbulence_model != AGX_TURB_NONE)
     return fail("turbulence_model %d is not built (laminar / inviscid only)",
                 cfg->turbulence_model);
+#endif
   if (cfg->inv_flux_jacobian != AGX_JACOBIAN_RUSANOV &&
       cfg->inv_flux_jacobian != AGX_JACOBIAN_APPROX_ROE)
     return fail("inv_flux_jacobian %d is not one of rusanov / approximateRoe",
@@ -946,6 +977,11 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
     for (int cc = 0; cc < 4; ++cc) d.fa[q][cc] = pl(PL_FA + 4 * q + cc);
   }
   b.state_is_a = true;
+#if AGX_NEQ == 7
+  d.specrad_t = pl(PL_SPECRAD_T); d.a_t = pl(PL_A_T); d.ainv_t = pl(PL_AINV_T);
+  d.viscp = pl(PL_VISC);
+  for (int q = 0; q < 3; ++q) d.turb3[q] = pl(PL_TURB3 + q);
+#endif
   if (c->sp.implicit && is_block_solver(c)) {
     // a_, aInv_ (25 planes each) and velocityGrad_ (9) of the block-matrix solvers
     const size_t n = (size_t)d.nplane * (2 * AGX_NJ + 9);
@@ -995,10 +1031,12 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
     double* wp[1] = {d.wid[q]};
     if (upload_aos(c, b, wsrc[q], wp, 1, ci, cj, ck, d.ng)) return 1;
   }
+#if AGX_FAST
   if (d.d2.base) {
     const long n = (long)d.d2.Pi * d.d2.Pj * (d.nk + 2 * d.ng);
     hipLaunchKernelGGL(k_d2_geo, dim3((n + 255) / 256), dim3(256), 0, c->stream, d);
   }
+#endif
   HIPCHK(hipGetLastError());
   if (g->wall_dist) {
     double* wp[1] = {d.wdist};
@@ -1193,8 +1231,17 @@ int agx_state_upload(agx_ctx* c, int id, const double* state) {
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
   const BlockDev& d = b.d;
-  return upload_aos(c, b, state, d.state, AGX_NEQ, d.ni + 2 * d.ng,
-                    d.nj + 2 * d.ng, d.nk + 2 * d.ng, d.ng);
+  if (upload_aos(c, b, state, d.state, AGX_NEQ, d.ni + 2 * d.ng,
+                 d.nj + 2 * d.ng, d.nk + 2 * d.ng, d.ng))
+    return 1;
+#if AGX_NEQ == 7
+  // gridLevel::AuxillaryAndWidths main.cpp:169: viscosity_ before the first iteration
+  // (the rans wall ghost states read the viscosity_ of the LAST UpdateAuxillaryVariables)
+  hipLaunchKernelGGL(k_aux_field, dim3((d.nplane + 255) / 256), dim3(256), 0, c->stream, d,
+                     c->gas, 1, d.viscp);
+  HIPCHK(hipGetLastError());
+#endif
+  return 0;
 }
 
 static int field_info(Block& b, int field, double* const** p, int* ncomp, int* ghost) {
@@ -1215,9 +1262,11 @@ static int field_info(Block& b, int field, double* const** p, int* ncomp, int* g
 
 // x of the D2 LU-SGS path <-> the SoA planes the field transfers use
 static int d2_x_copy(agx_ctx* c, Block& b, int to_d2) {
+#if AGX_FAST
   const long n = (long)b.d.d2.Pi * b.d.d2.Pj * (b.d.nk + 2 * b.d.ng);
   hipLaunchKernelGGL(k_d2_x_copy, dim3((n + 255) / 256), dim3(256), 0, c->stream, b.d, to_d2);
   HIPCHK(hipGetLastError());
+#endif
   return 0;
 }
 
@@ -1333,7 +1382,14 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
     }
     Timer t(c, G_VISC);
     for (auto& blk : c->blocks)
-      if (c->visc_gather || c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH) {
+#if AGX_NEQ == 7
+      {
+        hipLaunchKernelGGL(k_visc_residual_rans, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
+                           0, c->stream, blk.d, c->gas, c->sp, cfl,
+                           c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH ? 1 : 0);
+      }
+#else
+      if (!AGX_FAST || c->visc_gather || c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH) {
         // (centralFourth reaches two cells to either side of a face: served by the
         // one-thread-per-cell form, whose stencil comes straight from the planes)
         hipLaunchKernelGGL(k_visc_residual, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
@@ -1350,6 +1406,7 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
                              vb, c->gas, c->sp, cfl, kchunk);
           continue;
         }
+#if AGX_FAST
         // 62 x 6 owned cells per workgroup, k cut into chunks so that >= ~4
         // workgroups per CU exist (the first pass of a chunk only primes the k-face)
         const int gx = (vb.ni + VT_OI - 1) / VT_OI, gy = (vb.nj + VT_OJ - 1) / VT_OJ;
@@ -1358,7 +1415,9 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
         nz = (vb.nk + kchunk - 1) / kchunk;
         hipLaunchKernelGGL(k_visc_tile, dim3(gx, gy, nz), dim3(VT_L, VT_R), 0, c->stream,
                            make_slab(vb), c->gas, c->sp, cfl, kchunk);
+#endif
       }
+#endif  // AGX_NEQ == 7
     if (c->sp.implicit && c->sp.block)
       for (auto& blk : c->blocks)
         hipLaunchKernelGGL(k_block_diag_visc, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK, 0,
@@ -1388,6 +1447,7 @@ int agx_phase_implicit_begin(agx_ctx* c) {
   c->sp.un_is_u = c->state_is_time_n ? 1 : 0;   // (read by every rhs_b of this iteration)
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
+#if AGX_FAST
     if (b.d2.base) {
       // diagonal terms, b and x0 straight into the D2 arrays of the sweeps
       const dim3 grid((b.d2.Pi + TT - 1) / TT, (b.d2.Pj + TT - 1) / TT, b.nk + 2 * b.ng);
@@ -1397,6 +1457,7 @@ int agx_phase_implicit_begin(agx_ctx* c) {
                          (c->sp.requires_init || conn) ? 1 : 0);
       continue;
     }
+#endif
     if (!c->sp.requires_init)   // x_[bb].Zero() incl. ghosts, linearSolver.cpp:141
       hipLaunchKernelGGL(k_zero5, dim3((b.nplane + 255) / 256), dim3(256), 0,
                          c->stream, planes(b.x), b.nplane);
@@ -1449,6 +1510,7 @@ int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
     Timer t(c, G_MRESID);
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       const BlockDev& b = c->blocks[n].d;
+#if AGX_FAST
       if (b.d2.base) {
         // (position chunk, k) pairs dealt to the XCDs band by band, see the kernel
         const long nwg = mresid_wgs(c, b);
@@ -1457,6 +1519,7 @@ int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
         if (reduce_norms(c, n, nwg)) return 1;
         continue;
       }
+#endif
       const dim3 grid = cell_grid(b, CELL_BLOCK);
       hipLaunchKernelGGL(k_matrix_resid, grid, CELL_BLOCK, 0, c->stream, b,
                          c->gas, c->sp, c->partials);
@@ -1610,8 +1673,9 @@ int agx_rccl_exchange_create(agx_ctx* c, const void* id128, int nranks, int rank
 // gridLevel::GetBoundaryConditions (state) / lusgs::Relax, dplur::Relax (update):
 // local connections, then the slabs of connections to other ranks
 int agx_halo_exchange(agx_ctx* c, int what) {
-  if (what < AGX_HALO_STATE || what > AGX_HALO_VELGRAD_B) return fail("bad halo selector %d", what);
-  if (what >= AGX_HALO_VELGRAD_A && !(c->sp.implicit && c->sp.block))
+  if (what < AGX_HALO_STATE || what > AGX_HALO_TURB) return fail("bad halo selector %d", what);
+  if (what == AGX_HALO_TURB && AGX_NEQ != 7) return fail("AGX_HALO_TURB: rans library only");
+  if (what >= AGX_HALO_VELGRAD_A && what <= AGX_HALO_VELGRAD_B && !(c->sp.implicit && c->sp.block))
     return fail("velocity gradients are kept (and exchanged) for the block-matrix solvers only");
   if (agx_halo_swap_local(c, what)) return 1;
   if (c->remote.empty()) return 0;
@@ -1702,6 +1766,8 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
       if (agx_halo_exchange(c, AGX_HALO_VELGRAD_A)) return 1;
       if (agx_halo_exchange(c, AGX_HALO_VELGRAD_B)) return 1;
     }
+    // ... and of eddyViscosity_, f1_, f2_ (SwapTurbVars :389-392), rans
+    if (AGX_NEQ == 7 && !c->conns.empty() && agx_halo_exchange(c, AGX_HALO_TURB)) return 1;
     // mgSolution::ImplicitUpdate :209-244; lusgs::Relax linearSolver.cpp:430-470;
     // dplur::Relax :509-535
     if (agx_phase_implicit_begin(c)) return 1;

@@ -10,8 +10,11 @@
 #include <hip/hip_runtime.h>
 #include "../../include/aither_gfx950.h"
 
+#ifndef AGX_NEQ
 #define AGX_NEQ 5
+#endif
 #define AGX_EPS 1.0e-30  // include/macros.hpp.in:20
+#define AGX_TURB_MIN 1.0e-20
 
 namespace agx {
 
@@ -82,6 +85,8 @@ __device__ __forceinline__ void prim_to_cons(const GasDev& g, const double* s,
   u[2] = s[0] * s[2];
   u[3] = s[0] * s[3];
   u[4] = rho_energy(g, s);
+#pragma unroll
+  for (int e = 5; e < AGX_NEQ; ++e) u[e] = s[0] * s[e];    // rho k, rho omega
 }
 // primitive(cons, phys) primitive.hpp:152-178, idealGas::PressFromEnergy
 // eos.cpp:40-52, TemperatureFromSpecEnergy thermodynamic.cpp:108-114
@@ -95,6 +100,10 @@ __device__ __forceinline__ void cons_to_prim(const GasDev& g, const double* u,
   s[3] = u[3] * ir;
   // p = rho R T, T = (E/rho - |v|^2/2 - hf) / cv  =>  p = (rhoE - rho(...)) / n
   s[4] = (u[4] - rho * (g.hf + 0.5 * dot3(s + 1, s + 1))) * g.inv_n;
+  // turbulence variables with primitive::LimitTurb (primitive.cpp:100-106;
+  // turbModel::TkeMin / OmegaMin turbulence.hpp:72-73)
+#pragma unroll
+  for (int e = 5; e < AGX_NEQ; ++e) s[e] = fmax(u[e] / rho, AGX_TURB_MIN);
 }
 // UpdatePrimWithCons primitive.hpp:206-231
 __device__ __forceinline__ void update_prim_with_cons(const GasDev& g,
@@ -289,6 +298,8 @@ __device__ __forceinline__ void phys_flux(const GasDev& g, const double* s,
   f[2] = m * s[2] + s[4] * n[1];
   f[3] = m * s[3] + s[4] * n[2];
   f[4] = vn * rho_enthalpy(g, s);
+#pragma unroll
+  for (int e = 5; e < AGX_NEQ; ++e) f[e] = m * s[e];
 }
 
 // RoeFlux inviscidFlux.hpp:260-382 with RoeAveragedState primitive.hpp:245-280
@@ -327,6 +338,8 @@ __device__ __forceinline__ void roe_flux(const GasDev& g, const double* l,
   diss[2] = wss * (roe[2] - aR * n[1]);
   diss[3] = wss * (roe[3] - aR * n[2]);
   diss[4] = wss * (hR - aR * vnR);
+#pragma unroll
+  for (int e = 5; e < AGX_NEQ; ++e) diss[e] = wss * roe[e];
   // entropy
   ws = fabs(vnR);
   wss = ws * (d[0] - d[4] * inv_a2);
@@ -350,6 +363,12 @@ __device__ __forceinline__ void roe_flux(const GasDev& g, const double* l,
   diss[2] += wss * (roe[2] + aR * n[1]);
   diss[3] += wss * (roe[3] + aR * n[2]);
   diss[4] += wss * (hR + aR * vnR);
+#pragma unroll
+  for (int e = 5; e < AGX_NEQ; ++e) {
+    diss[e] += wss * roe[e];
+    // turbulence waves, inviscidFlux.hpp:363-372
+    diss[e] += fabs(vnR) * (rhoR * d[e] + roe[e] * d[0] - d[4] * roe[e] * inv_a2);
+  }
   double fl[AGX_NEQ], fr[AGX_NEQ];
   phys_flux(g, l, n, fl);
   phys_flux(g, r, n, fr);
@@ -394,6 +413,8 @@ __device__ __forceinline__ void ausm_flux(const GasDev& g, const double* l,
   f[2] = l[0] * vl * l[2] + r[0] * vr * r[2] + ps * n[1];
   f[3] = l[0] * vl * l[3] + r[0] * vr * r[3] + ps * n[2];
   f[4] = vl * rho_enthalpy(g, l) + vr * rho_enthalpy(g, r);
+#pragma unroll
+  for (int e = 5; e < AGX_NEQ; ++e) f[e] = l[0] * vl * l[e] + r[0] * vr * r[e];
 }
 
 template <int FLUX>
@@ -432,7 +453,8 @@ __device__ __forceinline__ void off_diagonal(const GasDev& g, bool viscous,
                                              const double* s, const double* du,
                                              const double* area, double mu,
                                              double dist, bool positive,
-                                             double* out, const double* diag = nullptr) {
+                                             double* out, const double* diag = nullptr,
+                                             double mut = 0.0, double f1 = 0.0) {
   double su[AGX_NEQ], fo[AGX_NEQ], fn[AGX_NEQ];
   update_prim_with_cons(g, s, du, su);
   if (diag) {
@@ -446,11 +468,23 @@ __device__ __forceinline__ void off_diagonal(const GasDev& g, bool viscous,
   phys_flux(g, s, area, fo);
   phys_flux(g, su, area, fn);
   double sr = 0.5 * area[3] * (fabs(dot3(s + 1, area)) + sound_speed(g, s));
-  if (viscous) sr += area[3] * fast_rcp(dist) * visc_max_term(g, s[0]) * visc_term(g, mu);
+  if (viscous)
+    sr += area[3] * fast_rcp(dist) * visc_max_term(g, s[0]) *
+          (AGX_NEQ > 5 ? g.scaling * (mu * g.inv_prandtl + mut / 0.9) : visc_term(g, mu));
   const double sg = positive ? 1.0 : -1.0;
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e)
+  for (int e = 0; e < 5; ++e)
     out[e] = 0.5 * area[3] * (fn[e] - fo[e]) + sg * du[e] * sr;
+  if (AGX_NEQ > 5) {
+    // turbulence entries: no flux change (fluxJacobian.cpp:145-148); spectral radius
+    // turbModel::FaceSpectralRadius turbulence.hpp:309-330 = InviscidFaceSpectralRadius
+    // (turbulence.cpp:174-186) + turbKWSst::ViscousFaceSpectralRadius (:817-831)
+    const double vn = dot3(s + 1, area);
+    double tsr = positive ? 0.5 * area[3] * fabs(vn + fabs(vn)) : 0.5 * area[3] * fabs(vn - fabs(vn));
+    tsr += g.scaling * (area[3] / dist) / s[0] * (mu + (f1 * 0.85 + (1.0 - f1) * 1.0) * mut);
+#pragma unroll
+    for (int e = 5; e < AGX_NEQ; ++e) out[e] = sg * du[e] * tsr;
+  }
 }
 
 // ---- block-matrix solvers (blusgs / bdplur): 5 x 5 flow Jacobians, row major ----
@@ -668,11 +702,27 @@ __device__ __forceinline__ void extrap_hold(const double* bnd, double factor,
 struct NrDev { double dt, sn[AGX_NEQ], pg[3], vg[9], avg_mach, max_mach; };
 
 // GetGhostState; returns false for a BC variant this build does not cover
+// primitive::ApplyFarfieldTurbBC primitive.cpp:83-98 (rans builds)
+__device__ inline void apply_farfield_turb(const GasDev& g, double* s, const double* vel,
+                                           double intensity, double ratio) {
+  if (AGX_NEQ > 5) {
+    const double q = intensity * sqrt(dot3(vel, vel));
+    s[AGX_NEQ - 2] = fmax(1.5 * q * q, AGX_TURB_MIN);
+    s[AGX_NEQ - 1] = fmax(s[0] * s[AGX_NEQ - 2] / (ratio * viscosity(g, temperature(g, s))),
+                          AGX_TURB_MIN);
+  }
+}
+// nu_w: kinematic viscosity of the wall-adjacent cell (rans viscous walls,
+// procBlock.cpp:2814-2820)
 __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
                                    const double* area_unit, int surf,
                                    const agx_bc_state& d, int layer,
                                    double wall_dist, double* gh,
-                                   const NrDev* nr = nullptr) {
+                                   const NrDev* nr = nullptr, double nu_w = 0.0) {
+  // rans: the other boundary types are not built (as in the oracle)
+  if (AGX_NEQ > 5 && bc != AGX_BC_SLIPWALL && bc != AGX_BC_VISCOUSWALL &&
+      bc != AGX_BC_CHARACTERISTIC)
+    return false;
 #pragma unroll
   for (int e = 0; e < AGX_NEQ; ++e) gh[e] = in[e];
   const double sgn = (surf % 2 == 1) ? -1.0 : 1.0;
@@ -695,20 +745,30 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
         const double tg = t - d.wall_heat_flux / conductivity(g, t) * 2.0 * wall_dist;
         gh[0] = gh[4] / (g.R * tg);
       }
+      if (AGX_NEQ > 5) {
+        // low-Re wall, ghostStates.cpp:261-279: k = 0 at the face, Menter's wall omega
+        // (WallBeta = beta1 = 0.075)
+        gh[AGX_NEQ - 2] = -1.0 * in[AGX_NEQ - 2];
+        const double w_wall = g.scaling * g.scaling * 60.0 * nu_w / (wall_dist * wall_dist * 0.075);
+        gh[AGX_NEQ - 1] = 2.0 * w_wall - in[AGX_NEQ - 1];
+        if (layer > 1) gh[AGX_NEQ - 1] = layer * gh[AGX_NEQ - 1] - w_wall;
+      }
       return true;
     }
     case AGX_BC_CHARACTERISTIC:
     case AGX_BC_INLET: {
       if (bc == AGX_BC_INLET && d.is_nonreflecting && !nr) return false;
-      const double fs[AGX_NEQ] = {d.density, d.velocity[0], d.velocity[1],
-                                  d.velocity[2], d.pressure};
+      const double fs[5] = {d.density, d.velocity[0], d.velocity[1], d.velocity[2],
+                            d.pressure};
       const double vn = dot3(in + 1, n);
       const double c = sound_speed(g, in);
       const double mach = fabs(vn) / c;
       const bool inflow = vn < 0.0;
       bool extrap = true;
       if (mach >= 1.0 && (inflow || bc == AGX_BC_INLET)) {
-        for (int e = 0; e < AGX_NEQ; ++e) gh[e] = fs[e];
+        for (int e = 0; e < 5; ++e) gh[e] = fs[e];
+        for (int e = 5; e < AGX_NEQ; ++e) gh[e] = 0.0;
+        apply_farfield_turb(g, gh, fs + 1, d.turb_intensity, d.eddy_visc_ratio);
         if (bc == AGX_BC_INLET) extrap = false;   // ghostStates.cpp:412-424
       } else if (mach >= 1.0) {
         // supersonic outflow: interior
@@ -731,6 +791,7 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
           const double dp = fs[4] - gh[4];
           gh[0] = fs[0] - dp / (c * c);
           for (int q = 0; q < 3; ++q) gh[1 + q] = fs[1 + q] - n[q] * dp / rc;
+          apply_farfield_turb(g, gh, fs + 1, d.turb_intensity, d.eddy_visc_ratio);
         }
       } else {
         const double rc = in[0] * c;
@@ -746,6 +807,8 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
         if (layer > 1) {
           extrap_hold(gh, (double)layer, in, t);
           for (int e = 0; e < AGX_NEQ; ++e) gh[e] = t[e];
+          // (whatever the flow direction, ghostStates.cpp:381-387)
+          apply_farfield_turb(g, gh, fs + 1, d.turb_intensity, d.eddy_visc_ratio);
         }
       }
       return true;

@@ -41,6 +41,15 @@ struct BlockDev {
   double* am;
   double* aminv;
   double* vg;
+  // 7-equation (rans) build, null otherwise: turbulence part of specRadius_ / a_ /
+  // aInv_ (uncoupledScalar), viscosity_ of the last UpdateAuxillaryVariables (the
+  // wall ghost states read it one iteration late, procBlock.cpp:2814), and
+  // eddyViscosity_, f1_, f2_ of the cells
+  double* specrad_t;
+  double* a_t;
+  double* ainv_t;
+  double* viscp;
+  double* turb3[3];
   double* wdist;              // wallDist_                procBlock.hpp:88
   D2Dev d2;                   // diagonal-ordered arrays of the LU-SGS path (agx_lusgs.hpp)
   const agx_bc_surface* surf; // boundaryConditions      boundaryConditions.hpp:231
@@ -67,12 +76,25 @@ struct NormPartial { double l2[AGX_NEQ]; double vmax; long long lin; };
 
 // All planes of a block live in ONE slab, plane p at base + p * nplane, so a
 // kernel needs a single base pointer (2 SGPRs) instead of ~60 plane pointers.
+// (AGX_NEQ = 5; the 7-equation rans build of the same sources adds the planes of the
+// turbulence part of the spectral radius / diagonal, the lagged viscosity_ and
+// eddyViscosity_, f1_, f2_)
 enum {
-  PL_STATE_A = 0, PL_STATE_B = 5, PL_RESID = 10, PL_CONSN = 15, PL_CONSNM1 = 20,
-  PL_X = 25, PL_XOLD = 30, PL_FA = 35 /* + 4*d + c */, PL_VOL = 47, PL_CEN = 48,
-  PL_WID = 51, PL_SPECRAD = 54, PL_DT = 55, PL_A = 56, PL_AINV = 57, PL_WDIST = 58,
-  PL_COUNT = 59
+  PL_STATE_A = 0, PL_STATE_B = AGX_NEQ, PL_RESID = 2 * AGX_NEQ, PL_CONSN = 3 * AGX_NEQ,
+  PL_CONSNM1 = 4 * AGX_NEQ, PL_X = 5 * AGX_NEQ, PL_XOLD = 6 * AGX_NEQ,
+  PL_FA = 7 * AGX_NEQ /* + 4*d + c */, PL_VOL = PL_FA + 12, PL_CEN = PL_VOL + 1,
+  PL_WID = PL_CEN + 3, PL_SPECRAD = PL_WID + 3, PL_DT = PL_SPECRAD + 1, PL_A = PL_DT + 1,
+  PL_AINV = PL_A + 1, PL_WDIST = PL_AINV + 1,
+#if AGX_NEQ == 7
+  PL_SPECRAD_T = PL_WDIST + 1, PL_A_T, PL_AINV_T, PL_VISC, PL_TURB3 /* mut, f1, f2 */,
+  PL_COUNT = PL_TURB3 + 3
+#else
+  PL_COUNT = PL_WDIST + 1
+#endif
 };
+// the LDS-tiled / diagonal-ordered production kernels are written for the
+// 5-equation set; the 7-equation build runs on the one-thread-per-cell kernels
+#define AGX_FAST (AGX_NEQ == 5)
 struct SlabDev {               // compact view used by the marching kernel
   double* base;
   long nplane, sx, sxy;
@@ -237,7 +259,7 @@ k_inv_residual(BlockDev b, GasDev g, SolverDev sp, double cfl) {
   constexpr int NS = 2 * H + 1;
   const long q = b.idx(i, j, k);
   double res[AGX_NEQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  double sr = 0.0;
+  double sr = 0.0, srt = 0.0;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const long s = b.stride(d);
@@ -258,10 +280,19 @@ k_inv_residual(BlockDev b, GasDev g, SolverDev sp, double cfl) {
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) res[e] += f[e] * au[3];
     sr += inv_cell_spec_rad(g, st[H], al, au);
+    if (AGX_NEQ > 5) {
+      // turbModel::InviscidCellSpectralRadius turbulence.cpp:162-172
+      const double v[3] = {0.5 * (al[0] + au[0]), 0.5 * (al[1] + au[1]), 0.5 * (al[2] + au[2])};
+      srt += fabs(dot3(st[H] + 1, v)) * fast_rsqrt(dot3(v, v)) * (0.5 * (al[3] + au[3]));
+    }
   }
   store5(b.resid, q, res);
   b.specrad[q] = sr;
   if (sp.implicit) b.a[q] = sr;
+  if (AGX_NEQ > 5) {
+    b.specrad_t[q] = srt;
+    if (sp.implicit) b.a_t[q] = srt;
+  }
   if (!sp.viscous)
     b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (b.vol[q] / fmax(sr, 0.0));
 }
@@ -536,6 +567,7 @@ k_residual_march(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
   }
 }
 
+#if AGX_FAST
 // ---------------------------------------------------------------------------
 // Inviscid residual, tiled marching form with LDS-staged planes (production).
 //
@@ -1101,6 +1133,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
   }
 }
 
+#endif  // AGX_FAST
 // ---------------------------------------------------------------------------
 // Viscous residual, one thread per cell, six faces.  Counterpart of
 // procBlock::CalcViscFluxI/J/K procBlock.cpp:1233-2135 (laminar, central
@@ -1316,6 +1349,200 @@ k_visc_residual(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth) {
   b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (vol / fmax(sr, 0.0));
 }
 
+#if AGX_NEQ == 7
+// ---------------------------------------------------------------------------
+// rans (k-omega SST 2003): viscous residual with eddy viscosity, the diffusion of k
+// and omega, the turbulence source terms and the turbulence part of the spectral
+// radius / scalar diagonal, one thread per cell.  procBlock::CalcViscFluxI/J/K
+// (procBlock.cpp:1233-2135), viscousFlux::CalcFlux (viscousFlux.cpp:58-135),
+// turbKWSst (turbulence.cpp:573-840, turbulence.hpp:489-606), CalcSrcTerms
+// (procBlock.cpp:5956-6027).
+constexpr double SST_BETA_STAR = 0.09, SST_SIGMA_K1 = 0.85, SST_SIGMA_K2 = 1.0,
+                 SST_SIGMA_W1 = 0.5, SST_SIGMA_W2 = 0.856, SST_BETA1 = 0.075,
+                 SST_BETA2 = 0.0828, SST_GAMMA1 = 5.0 / 9.0, SST_GAMMA2 = 0.44, SST_A1 = 0.31,
+                 SST_KPROD2DEST = 10.0;
+__device__ __forceinline__ double sst_blend(double c1, double c2, double f1) {
+  return f1 * c1 + (1.0 - f1) * c2;
+}
+__device__ __forceinline__ double sst_cdkw(const double* s, const double* kg, const double* wg) {
+  return fmax(2.0 * s[0] * SST_SIGMA_W2 / s[6] * dot3(kg, wg), 1.0e-10);
+}
+// turbKWSst::EddyViscAndBlending turbulence.cpp:695-727; vg[3 r + c]
+__device__ inline void sst_eddy_visc_blending(const GasDev& g, const double* s, const double* vg,
+                                              const double* kg, const double* wg, double mu,
+                                              double wall_dist, double& mut, double& f1,
+                                              double& f2) {
+  const double wd = wall_dist + AGX_EPS;
+  const double alpha1 = g.scaling * sqrt(s[5]) / (SST_BETA_STAR * s[6] * wd);
+  const double alpha2 = g.scaling * g.scaling * 500.0 * mu / (wd * wd * s[0] * s[6]);
+  const double cdkw = sst_cdkw(s, kg, wg);
+  const double alpha3 = 4.0 * s[0] * SST_SIGMA_W2 * s[5] / (cdkw * wd * wd);
+  const double arg1 = fmin(fmax(alpha1, alpha2), alpha3);
+  f1 = tanh(pow(arg1, 4.0));
+  const double arg2 = fmax(2.0 * alpha1, alpha2);
+  f2 = tanh(arg2 * arg2);
+  double ss = 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double sy = 0.5 * (vg[3 * r + c] + vg[3 * c + r]);
+      ss += sy * sy;
+    }
+  const double strain = sqrt(2.0 * ss);
+  mut = s[0] * SST_A1 * s[5] / fmax(SST_A1 * s[6], g.scaling * strain * f2);
+}
+// Green-Gauss gradients of k and omega at the lower d-face of cell qU
+// (ScalarGradGG utility.cpp:138-188 on the face-centred dual volume)
+__device__ inline void turb_face_grads(const BlockDev& b, int d, long qU, double* kg,
+                                       double* wg) {
+  const long sd = b.stride(d), qL = qU - sd;
+  double au[3][3], al[3][3];
+  {
+    double a0[3], a1[3], a2[3];
+    area_vec(b, d, qU, a0); area_vec(b, d, qU + sd, a1); area_vec(b, d, qU - sd, a2);
+    for (int r = 0; r < 3; ++r) { au[d][r] = 0.5 * (a0[r] + a1[r]); al[d][r] = 0.5 * (a0[r] + a2[r]); }
+  }
+  for (int t = 0; t < 3; ++t) {
+    if (t == d) continue;
+    const long st = b.stride(t);
+    double a0[3], a1[3];
+    area_vec(b, t, qU + st, a0); area_vec(b, t, qL + st, a1);
+    for (int r = 0; r < 3; ++r) au[t][r] = 0.5 * (a0[r] + a1[r]);
+    area_vec(b, t, qU, a0); area_vec(b, t, qL, a1);
+    for (int r = 0; r < 3; ++r) al[t][r] = 0.5 * (a0[r] + a1[r]);
+  }
+  const double inv_vol = 1.0 / (0.5 * (b.vol[qL] + b.vol[qU]));
+  for (int f = 0; f < 2; ++f) {
+    const double* pl = b.state[5 + f];
+    double vu[3], vl[3];
+    const double fL = pl[qL], fU = pl[qU];
+    vl[d] = fL; vu[d] = fU;
+    for (int t = 0; t < 3; ++t) {
+      if (t == d) continue;
+      const long st = b.stride(t);
+      vu[t] = 0.25 * (fL + fU + pl[qU + st] + pl[qL + st]);
+      vl[t] = 0.25 * (fL + fU + pl[qU - st] + pl[qL - st]);
+    }
+    double* out = f == 0 ? kg : wg;
+    for (int r = 0; r < 3; ++r)
+      out[r] = (vu[0] * au[0][r] - vl[0] * al[0][r] + vu[1] * au[1][r] - vl[1] * al[1][r] +
+                vu[2] * au[2][r] - vl[2] * al[2][r]) * inv_vol;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  double res[AGX_NEQ];
+  load5(b.resid, q, res);
+  double sr = b.specrad[q], srt = b.specrad_t[q];
+  double diag = sp.implicit ? b.a[q] : 0.0, diag_t = sp.implicit ? b.a_t[q] : 0.0;
+  double sc[AGX_NEQ];
+  load5(b.state, q, sc);
+  const double muc = viscosity(g, temperature(g, sc));
+  const double vol = b.vol[q];
+  double vgc[9], kgc[3] = {0, 0, 0}, wgc[3] = {0, 0, 0}, mutc = 0.0, f1c = 0.0, f2c = 0.0;
+  for (int e = 0; e < 9; ++e) vgc[e] = 0.0;
+  for (int d = 0; d < 3; ++d) {
+    const long s = b.stride(d);
+    double mut_lo = 0.0, f1_lo = 0.0;
+    for (int up = 0; up < 2; ++up) {
+      const long qU = q + (up ? s : 0), qL = qU - s;
+      double grad[3][4], sf[AGX_NEQ], muf, n[4], G[9], kg[3], wg[3];
+      visc_face_terms(b, g, d, qU, fourth != 0, grad, sf, muf);
+      turb_face_grads(b, d, qU, kg, wg);
+      load_area(b, d, qU, n);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) G[3 * r + c] = grad[r][c];
+      // state.LimitTurb; wall distance at the face by the two-cell rule
+      sf[5] = fmax(sf[5], AGX_TURB_MIN);
+      sf[6] = fmax(sf[6], AGX_TURB_MIN);
+      const double wU = b.wid[d][qL], wD = b.wid[d][qU];
+      const double cD = wD / (wU + wD), cU = wU / (wU + wD);
+      double wdist = cD * b.wdist[qU] + cU * b.wdist[qL];
+      if (wdist < 0.0 && wdist > -1.0e-10) wdist = 0.0;
+      double mut, f1, f2;
+      sst_eddy_visc_blending(g, sf, G, kg, wg, muf, wdist, mut, f1, f2);
+      // viscousFlux::CalcFlux
+      const double mu = g.scaling * muf, mt = g.scaling * mut;
+      const double lambda = -(2.0 / 3.0) * (mu + mt);
+      const double trace = grad[0][0] + grad[1][1] + grad[2][2];
+      double tau[3];
+      for (int r = 0; r < 3; ++r) {
+        const double mm = (grad[r][0] + grad[0][r]) * n[0] + (grad[r][1] + grad[1][r]) * n[1] +
+                          (grad[r][2] + grad[2][r]) * n[2];
+        tau[r] = lambda * trace * n[r] + (mu + mt) * mm;
+      }
+      const double kk = conductivity(g, temperature(g, sf)) * g.scaling;
+      const double kt = mt * g.cp / 0.9;
+      const double tg = grad[0][3] * n[0] + grad[1][3] * n[1] + grad[2][3] * n[2];
+      double f[AGX_NEQ];
+      f[0] = 0.0;
+      f[1] = tau[0]; f[2] = tau[1]; f[3] = tau[2];
+      f[4] = dot3(tau, sf + 1) + (kk + kt) * tg;
+      f[5] = (mu + sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1) * mt) * dot3(kg, n);
+      f[6] = (mu + sst_blend(SST_SIGMA_W1, SST_SIGMA_W2, f1) * mt) * dot3(wg, n);
+      // this cell is the right cell of its lower face (+), the left of its upper (-)
+      for (int e = 0; e < AGX_NEQ; ++e) res[e] += (up ? -1.0 : 1.0) * f[e] * n[3];
+      for (int e = 0; e < 9; ++e) vgc[e] += (1.0 / 6.0) * G[e];
+      for (int r = 0; r < 3; ++r) { kgc[r] += (1.0 / 6.0) * kg[r]; wgc[r] += (1.0 / 6.0) * wg[r]; }
+      mutc += (1.0 / 6.0) * mut; f1c += (1.0 / 6.0) * f1; f2c += (1.0 / 6.0) * f2;
+      if (!up) { mut_lo = mut; f1_lo = f1; }
+    }
+    // ViscCellSpectralRadius spectralRadius.hpp:94-124 and turbKWSst::
+    // ViscousCellSpectralRadius turbulence.cpp:797-815 with the LOWER face's mut, f1
+    const double fmag = 0.5 * (b.fa[d][3][q] + b.fa[d][3][q + s]);
+    const double vsr = visc_max_term(g, sc[0]) *
+                       (g.scaling * (muc * g.inv_prandtl + mut_lo / 0.9)) * fmag * fmag / vol;
+    sr += vsr * sp.visc_cfl_coeff;
+    diag += 2.0 * vsr;
+    const double tvsr = g.scaling * (fmag * fmag / vol) / sc[0] *
+                        (muc + sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1_lo) * mut_lo);
+    srt += tvsr * sp.visc_cfl_coeff;
+    diag_t += 2.0 * tvsr;
+  }
+  // ---- source terms of the cell, turbKWSst::CalcTurbSrc turbulence.cpp:637-690 ----
+  {
+    const double inv_sc = 1.0 / g.scaling;
+    const double cdkw = sst_cdkw(sc, kgc, wgc);
+    const double gam = sst_blend(SST_GAMMA1, SST_GAMMA2, f1c);
+    const double beta = sst_blend(SST_BETA1, SST_BETA2, f1c);
+    const double tke_dest = inv_sc * SST_BETA_STAR * (sc[0] * sc[5] * sc[6] * 1.0);
+    const double omg_dest = inv_sc * beta * (sc[0] * sc[6] * sc[6]);
+    const double lambda = -(2.0 / 3.0) * mutc;
+    const double trace = vgc[0] + vgc[4] + vgc[8];
+    double ddot = 0.0;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        const double id = r == c ? 1.0 : 0.0;
+        const double tau = lambda * trace * id + mutc * (vgc[3 * r + c] + vgc[3 * c + r]) -
+                           2.0 / 3.0 * sc[0] * sc[5] * id;
+        ddot += tau * vgc[3 * c + r];
+      }
+    double tke_prod = fmax(fmin(g.scaling * ddot, SST_KPROD2DEST * tke_dest), 0.0);
+    const double omg_prod = fmax(gam * sc[0] / mutc * tke_prod, 0.0);
+    const double omg_cd = g.scaling * (1.0 - f1c) * cdkw;
+    res[5] -= (tke_prod - tke_dest) * vol;
+    res[6] -= (omg_prod - omg_dest + omg_cd) * vol;
+    const double src_sr = -2.0 * SST_BETA_STAR * sc[6] * vol * inv_sc;   // SrcSpecRad :739-747
+    srt -= src_sr;
+    diag_t -= src_sr;
+  }
+  store5(b.resid, q, res);
+  b.specrad[q] = sr;
+  b.specrad_t[q] = srt;
+  if (sp.implicit) { b.a[q] = diag; b.a_t[q] = diag_t; }
+  b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (vol / fmax(fmax(sr, srt), 0.0));
+  b.turb3[0][q] = mutc; b.turb3[1][q] = f1c; b.turb3[2][q] = f2c;
+  b.viscp[q] = muc;       // viscosity_ of this UpdateAuxillaryVariables, read next iteration
+}
+#endif  // AGX_NEQ == 7
+
 // Face-once form of k_visc_residual (production): a workgroup of 64 x 8 threads
 // owns a 63 x 7 column of cells and marches it along k.  Every thread evaluates
 // the viscous flux of its lower i-, lower j- and upper k-face; the upper i-face
@@ -1388,7 +1615,9 @@ k_visc_march(BlockDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
 }
 
 }  // namespace agx
+#if AGX_FAST
 #include "agx_visc_tile.hpp"
+#endif
 namespace agx {
 
 // ---------------------------------------------------------------------------
@@ -1466,10 +1695,12 @@ __global__ void k_bc_faces(BlockDev b, GasDev g, int viscous, int* err) {
   double area[4];
   load_area(b, d3, b.idx(c[0], c[1], c[2]), area);
   // wall distance of the wall-adjacent cell (procBlock.cpp:2813), heat-flux walls only
-  double wd = 0.0;
-  if (bc == AGX_BC_VISCOUSWALL && sf.state.is_heat_flux) {
+  double wd = 0.0, nu_w = 0.0;
+  if (bc == AGX_BC_VISCOUSWALL && (sf.state.is_heat_flux || AGX_NEQ > 5)) {
     c[d3] = st % 2 == 0 ? r3 - 1 : r3;
-    wd = b.wdist[b.idx(c[0], c[1], c[2])];
+    const long qa = b.idx(c[0], c[1], c[2]);
+    wd = b.wdist[qa];
+    if (AGX_NEQ > 5) nu_w = b.viscp[qa] / b.state[0][qa];
     c[d3] = r3;
   }
   // one thread fills all ghost layers of its surface cell: on i-surfaces the
@@ -1502,7 +1733,7 @@ __global__ void k_bc_faces(BlockDev b, GasDev g, int viscous, int* err) {
       nr.avg_mach = b.nr_mach[2 * sn];
       nr.max_mach = b.nr_mach[2 * sn + 1];
     }
-    if (!ghost_state(g, in, bc, area, st, sf.state, layer, wd, gh, is_nr ? &nr : nullptr)) {
+    if (!ghost_state(g, in, bc, area, st, sf.state, layer, wd, gh, is_nr ? &nr : nullptr, nu_w)) {
       *err = 1;
       return;
     }
@@ -1884,7 +2115,8 @@ __device__ __forceinline__ void add_off_diag(const BlockDev& b, const GasDev& g,
       block_off_diagonal(g, sp.viscous != 0, sn, du, area, mu, dist, lower, vgn, od);
     } else {
       if (sp.roe_jacobian) load5(b.state, q, sd);
-      off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od, sp.roe_jacobian ? sd : nullptr);
+      off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od, sp.roe_jacobian ? sd : nullptr,
+                   AGX_NEQ > 5 ? b.turb3[0][qn] : 0.0, AGX_NEQ > 5 ? b.turb3[1][qn] : 0.0);
     }
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) acc[e] += sign * od[e];
@@ -1901,11 +2133,24 @@ k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err) {
   if (i >= b.ni || j >= b.nj) return;
   const long q = b.idx(i, j, k);
   double dvt = (b.vol[q] * (1.0 + sp.zeta)) / (b.dt[q] * sp.theta);
-  if (sp.dual_time_cfl > 0.0) dvt += fmax(b.specrad[q], 0.0) / sp.dual_time_cfl;
+  if (sp.dual_time_cfl > 0.0)    // specRadius_.Max(): the larger of the flow and turbulence parts
+    dvt += fmax(fmax(b.specrad[q], AGX_NEQ > 5 ? b.specrad_t[q] : 0.0), 0.0) / sp.dual_time_cfl;
   const double a = b.a[q] * sp.relax + dvt;
   const double ainv = 1.0 / a;
   b.a[q] = a;
   b.ainv[q] = ainv;
+  double ainv_t = 0.0;
+  if (AGX_NEQ > 5) {
+    // turbulence part of the scalar diagonal (uncoupledScalar); the dual-time term
+    // uses specRadius_.Max()
+    double dvt_t = (b.vol[q] * (1.0 + sp.zeta)) / (b.dt[q] * sp.theta);
+    if (sp.dual_time_cfl > 0.0)
+      dvt_t += fmax(fmax(b.specrad[q], b.specrad_t[q]), 0.0) / sp.dual_time_cfl;
+    const double at = b.a_t[q] * sp.relax + dvt_t;
+    b.a_t[q] = at;
+    ainv_t = 1.0 / at;
+    b.ainv_t[q] = ainv_t;
+  }
   double x0[AGX_NEQ] = {0, 0, 0, 0, 0};
   if (sp.block) {
     // MultiplyOnDiagonal / AddOnDiagonal / Inverse, matMultiArray3d.hpp:96-111
@@ -1930,7 +2175,7 @@ k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err) {
   if (sp.requires_init) {
     rhs_b(b, g, sp, q, x0);
 #pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) x0[e] *= ainv;
+    for (int e = 0; e < AGX_NEQ; ++e) x0[e] *= e < 5 ? ainv : ainv_t;
   }
   store5(b.x, q, x0);
 }
@@ -1944,8 +2189,9 @@ __device__ __forceinline__ void apply_ainv(const BlockDev& b, const SolverDev& s
     mat_vec5(m, v, out);
   } else {
     const double ainv = b.ainv[q];
+    const double ainv_t = AGX_NEQ > 5 ? b.ainv_t[q] : 0.0;
 #pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) out[e] = v[e] * ainv;
+    for (int e = 0; e < AGX_NEQ; ++e) out[e] = v[e] * (e < 5 ? ainv : ainv_t);
   }
 }
 __global__ void k_zero5(Planes5 a, long n) {
@@ -2002,7 +2248,9 @@ __global__ void __launch_bounds__(256) k_lusgs_plane(BlockDev b, GasDev g, Solve
 }
 
 }  // namespace agx
+#if AGX_FAST
 #include "agx_lusgs_kernels.hpp"
+#endif
 namespace agx {
 
 // dplur::DPLUR linearSolver.cpp:473-507 (point Jacobi on the copied xold)
@@ -2047,8 +2295,9 @@ k_matrix_resid(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
       mat_vec5(m, xc, ax);
     } else {
       const double a = b.a[q];
+      const double at = AGX_NEQ > 5 ? b.a_t[q] : 0.0;
 #pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e) ax[e] = xc[e] * a;
+      for (int e = 0; e < AGX_NEQ; ++e) ax[e] = xc[e] * (e < 5 ? a : at);
     }
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) r[e] = -(ax[e] - acc[e] - rb[e]);

@@ -67,6 +67,10 @@ def run_pair(agx, oracle, case, steps, fields=("state", "residual", "dt"),
             for gb in sg.block_ids:
                 for f in SYNC_FIELDS:
                     sg.upload(f, gb, so.download(f, gb))
+                # (a state upload re-derives what the library keeps from the state at
+                # start-up -- the rans viscosity_ of AuxillaryAndWidths, main.cpp:169 --
+                # so the oracle gets the same call)
+                so.upload("state", gb, so.download("state", gb))
             sg.l2_first = None if so.l2_first is None else so.l2_first.copy()
         sg.step(nn), so.step(nn)
         assert len(sg.history) == len(so.history)

@@ -33,6 +33,11 @@ def test_product_library_exports_every_symbol():
         assert hasattr(lib, "agx_" + name), name
     api = aither_amd.load()
     assert b"gfx950" in api.version()
+    # the 7-equation (rans) build of the same sources exports the same C-ABI
+    assert os.path.exists(aither_amd.RANS_LIB_PATH)
+    lib7 = ctypes.CDLL(aither_amd.RANS_LIB_PATH)
+    for name in abi.SYMBOLS:
+        assert hasattr(lib7, "agx_" + name), name
 
 
 def test_product_library_fails_loudly_without_gpu():
