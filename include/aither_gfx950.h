@@ -1,4 +1,6 @@
-/* aither_gfx950.h -- C-ABI of libaither_gfx950.so
+/* aither_gfx950.h -- C-ABI of libaither_gfx950.so (5 equations: euler,
+ * navierStokes) and of libaither_gfx950_rans.so (7 equations: rans with k-omega
+ * SST 2003; the same sources built with -DAGX_NEQ=7, the same entry points).
  *
  * MI355X (gfx950) implementation of AITHER's per-iteration hot path:
  * ghost-cell fill, face reconstruction, inviscid/viscous fluxes, time step,
@@ -109,7 +111,7 @@ typedef struct agx_gas {
 
 /* solver configuration; one per context */
 typedef struct agx_config {
-  int32_t n_eq;              /* 5 (single species, no turbulence)          */
+  int32_t n_eq;              /* 5, or 7 = [rho, u, v, w, p, k, omega] in the rans library */
   int32_t n_ghost;           /* input::NumberGhostLayers (input.cpp:1127)  */
   int32_t recon;             /* AGX_RECON_*                                */
   int32_t limiter;           /* AGX_LIMITER_*                              */
