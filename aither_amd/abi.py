@@ -23,7 +23,7 @@ FIELD = {"state": 0, "residual": 1, "dt": 2, "spec_radius": 3, "cons_n": 4,
          "update": 5, "diagonal": 6, "temperature": 7, "viscosity": 8,
          "cons_nm1": 9, "vel_grad": 10, "temp_grad": 11, "dens_grad": 12,
          "press_grad": 13}
-HALO_STATE, HALO_UPDATE, HALO_VELGRAD_A, HALO_VELGRAD_B = 0, 1, 2, 3
+HALO_STATE, HALO_UPDATE, HALO_VELGRAD_A, HALO_VELGRAD_B, HALO_TURB = 0, 1, 2, 3, 4
 
 c_dp = C.POINTER(C.c_double)
 

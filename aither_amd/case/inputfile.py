@@ -193,8 +193,6 @@ class InputDeck:
             bad.append(f"equationSet {self.equation_set}")
         if self.equation_set == "rans" and self.turbulence_model != "sst2003":
             bad.append(f"turbulenceModel {self.turbulence_model}")
-        if self.equation_set == "rans" and self.matrix_solver not in ("lusgs", "dplur"):
-            bad.append("rans with a block-matrix solver")
         if self.thermodynamic_model != "caloricallyPerfect":
             bad.append("thermallyPerfect")
         if self.multigrid_levels != 1:

@@ -886,9 +886,8 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
     return fail("the 7-equation library serves equation_set rans (viscous) only");
   if (cfg->turbulence_model != AGX_TURB_SST2003)
     return fail("turbulence_model %d: only sst2003 is built", cfg->turbulence_model);
-  if (cfg->matrix_solver == AGX_SOLVER_BLUSGS || cfg->matrix_solver == AGX_SOLVER_BDPLUR ||
-      cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE)
-    return fail("rans: block-matrix solvers and approximateRoe are not built");
+  if (cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE)
+    return fail("rans: approximateRoe is not built");
 #else
   if (cfg->equation_set != AGX_EQN_EULER && cfg->equation_set != AGX_EQN_NAVIER_STOKES)
     return fail("equation_set %d: this library covers euler and navierStokes "
@@ -984,12 +983,15 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
 #endif
   if (c->sp.implicit && is_block_solver(c)) {
     // a_, aInv_ (25 planes each) and velocityGrad_ (9) of the block-matrix solvers
-    const size_t n = (size_t)d.nplane * (2 * AGX_NJ + 9);
+    // (+ 2 x 2 planes: diagonal of the turbulence block in the rans build)
+    const size_t n = (size_t)d.nplane * (2 * AGX_NJ + 9 + 4);
     HIPCHK(hipMalloc((void**)&b.blockmat, sizeof(double) * n));
     HIPCHK(hipMemsetAsync(b.blockmat, 0, sizeof(double) * n, c->stream));
     d.am = b.blockmat;
     d.aminv = b.blockmat + (size_t)d.nplane * AGX_NJ;
     d.vg = b.blockmat + (size_t)d.nplane * 2 * AGX_NJ;
+    d.am_t = d.vg + (size_t)d.nplane * 9;
+    d.aminv_t = d.am_t + (size_t)d.nplane * 2;
   }
   if (use_d2(c) && std::min(d.ni, d.nj) > KP_MAX_DIAG)
     return fail("LU-SGS: a block with min(ni, nj) = %d exceeds the %d cells per diagonal "
@@ -1418,11 +1420,13 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
 #endif
       }
 #endif  // AGX_NEQ == 7
+#if AGX_NEQ != 7     // (the rans viscous kernel accumulates its Jacobians itself)
     if (c->sp.implicit && c->sp.block)
       for (auto& blk : c->blocks)
         hipLaunchKernelGGL(k_block_diag_visc, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK, 0,
                            c->stream, blk.d, c->gas, c->sp,
                            c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH ? 1 : 0);
+#endif
     HIPCHK(hipGetLastError());
   }
   // the gradients of this residual's state feed the nonreflecting ghost states of

@@ -488,7 +488,8 @@ __device__ __forceinline__ void off_diagonal(const GasDev& g, bool viscous,
 }
 
 // ---- block-matrix solvers (blusgs / bdplur): 5 x 5 flow Jacobians, row major ----
-constexpr int AGX_NJ = AGX_NEQ * AGX_NEQ;
+constexpr int AGX_NF = 5;                 // flow equations (the block of the block solvers)
+constexpr int AGX_NJ = AGX_NF * AGX_NF;
 // fluxJacobian::InvFluxJacobian fluxJacobian.hpp:483-560 (one species, mf = 1)
 __device__ inline void inv_flux_jacobian(const GasDev& g, const double* s, const double* area,
                                          double* J) {
@@ -496,7 +497,7 @@ __device__ inline void inv_flux_jacobian(const GasDev& g, const double* s, const
   const double vn = dot3(s + 1, n);
   const double gm1 = g.gamma - 1.0;
   const double phi = 0.5 * gm1 * dot3(s + 1, s + 1);
-  double u[AGX_NEQ];
+  double u[AGX_NF];
   prim_to_cons(g, s, u);
   const double a1 = g.gamma * (u[4] / s[0]) - phi;    // primitive::Energy
   const double a3 = g.gamma - 2.0;
@@ -506,19 +507,19 @@ __device__ inline void inv_flux_jacobian(const GasDev& g, const double* s, const
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     J[1 + q] = 1.0 * n[q];
-    J[AGX_NEQ * (1 + q)] = phi * n[q] - s[1 + q] * vn;
+    J[AGX_NF * (1 + q)] = phi * n[q] - s[1 + q] * vn;
   }
-  J[AGX_NEQ * 4] = vn * (phi - a1);
+  J[AGX_NF * 4] = vn * (phi - a1);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
 #pragma unroll
     for (int r = 0; r < 3; ++r)
-      J[AGX_NEQ * (1 + r) + 1 + c] = r == c ? vn - a3 * n[c] * s[1 + c]
+      J[AGX_NF * (1 + r) + 1 + c] = r == c ? vn - a3 * n[c] * s[1 + c]
                                             : s[1 + r] * n[c] - gm1 * s[1 + c] * n[r];
-    J[AGX_NEQ * 4 + 1 + c] = a1 * n[c] - gm1 * s[1 + c] * vn;
-    J[AGX_NEQ * (1 + c) + 4] = gm1 * n[c];
+    J[AGX_NF * 4 + 1 + c] = a1 * n[c] - gm1 * s[1 + c] * vn;
+    J[AGX_NF * (1 + c) + 4] = gm1 * n[c];
   }
-  J[AGX_NEQ * 4 + 4] = g.gamma * vn;
+  J[AGX_NF * 4 + 4] = g.gamma * vn;
   const double h = 0.5 * area[3];
 #pragma unroll
   for (int q = 0; q < AGX_NJ; ++q) J[q] *= h;
@@ -530,20 +531,22 @@ __device__ inline void rusanov_flux_jacobian(const GasDev& g, const double* s, c
   const double sr = 0.5 * area[3] * (fabs(dot3(s + 1, area)) + sound_speed(g, s));
   inv_flux_jacobian(g, s, area, J);
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) J[AGX_NEQ * e + e] += positive ? sr : -sr;
+  for (int e = 0; e < AGX_NF; ++e) J[AGX_NF * e + e] += positive ? sr : -sr;
 }
 // fluxJacobian::ApproxTSLJacobian :660-758 (laminar, one species) times
 // DelprimitiveDelConservative :613-656; TauNormal utility.cpp:426-436.  vg[3 r + c]:
 // velocity gradient (only its trace and symmetric part enter)
 __device__ inline void tsl_jacobian(const GasDev& g, const double* s, double lam_visc,
                                     const double* area, double dist, bool left, const double* vg,
-                                    double* J) {
+                                    double* J, double turb_visc = 0.0) {
   const double t = temperature(g, s);
-  const double mu = g.scaling * lam_visc;
+  // (mu: laminar + eddy viscosity; the conductivity below gets its turbulent part)
+  const double mut = g.scaling * turb_visc;
+  const double mu = g.scaling * lam_visc + mut;
   const double* n = area;
   const double vn = dot3(s + 1, n);
   const double rho = s[0];
-  const double k = conductivity(g, t) * g.scaling;
+  const double k = conductivity(g, t) * g.scaling + mut * g.cp / 0.9;
   const double lambda = 0.0 - (2.0 / 3.0) * mu;
   const double trace = vg[0] + vg[4] + vg[8];
   double tau[3];
@@ -559,15 +562,15 @@ __device__ inline void tsl_jacobian(const GasDev& g, const double* s, double lam
   double T[AGX_NJ], P[AGX_NJ];
 #pragma unroll
   for (int q = 0; q < AGX_NJ; ++q) { T[q] = 0.0; P[q] = 0.0; }
-  T[AGX_NEQ * 4] = -k * t / (mu * rho) + 0.0;
+  T[AGX_NF * 4] = -k * t / (mu * rho) + 0.0;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
 #pragma unroll
     for (int r = 0; r < 3; ++r)
-      T[AGX_NEQ * (1 + r) + 1 + c] = third * n[c] * n[r] + (r == c ? 1.0 : 0.0);
-    T[AGX_NEQ * 4 + 1 + c] = fac * 0.5 * dist / mu * tau[c] + third * n[c] * vn + s[1 + c];
+      T[AGX_NF * (1 + r) + 1 + c] = third * n[c] * n[r] + (r == c ? 1.0 : 0.0);
+    T[AGX_NF * 4 + 1 + c] = fac * 0.5 * dist / mu * tau[c] + third * n[c] * vn + s[1 + c];
   }
-  T[AGX_NEQ * 4 + 4] = k / (mu * rho);
+  T[AGX_NF * 4 + 4] = k / (mu * rho);
   const double sc = area[3] * mu / dist;
 #pragma unroll
   for (int q = 0; q < AGX_NJ; ++q) T[q] *= sc;
@@ -575,26 +578,26 @@ __device__ inline void tsl_jacobian(const GasDev& g, const double* s, double lam
   P[0] = 1.0;
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    P[AGX_NEQ * (1 + q)] = -ir * s[1 + q];
-    P[AGX_NEQ * (1 + q) + 1 + q] = ir;
-    P[AGX_NEQ * 4 + 1 + q] = -gm1 * s[1 + q];
+    P[AGX_NF * (1 + q)] = -ir * s[1 + q];
+    P[AGX_NF * (1 + q) + 1 + q] = ir;
+    P[AGX_NF * 4 + 1 + q] = -gm1 * s[1 + q];
   }
-  P[AGX_NEQ * 4] = 0.5 * gm1 * dot3(s + 1, s + 1);
-  P[AGX_NEQ * 4 + 4] = gm1;
+  P[AGX_NF * 4] = 0.5 * gm1 * dot3(s + 1, s + 1);
+  P[AGX_NF * 4 + 4] = gm1;
 #pragma unroll
   for (int q = 0; q < AGX_NJ; ++q) J[q] = 0.0;
 #pragma unroll
-  for (int c = 0; c < AGX_NEQ; ++c)          // MatrixMultiply matrix.cpp:193-207
+  for (int c = 0; c < AGX_NF; ++c)          // MatrixMultiply matrix.cpp:193-207
 #pragma unroll
-    for (int r = 0; r < AGX_NEQ; ++r)
+    for (int r = 0; r < AGX_NF; ++r)
 #pragma unroll
-      for (int i = 0; i < AGX_NEQ; ++i) J[AGX_NEQ * r + i] += T[AGX_NEQ * r + c] * P[AGX_NEQ * c + i];
+      for (int i = 0; i < AGX_NF; ++i) J[AGX_NF * r + i] += T[AGX_NF * r + c] * P[AGX_NF * c + i];
 }
 // MatrixInverse matrix.cpp:57-103 (Gauss-Jordan with row exchanges); m becomes its
 // inverse; returns false for a singular matrix.  Fully unrolled, so the 50 doubles
 // stay in registers (row exchanges are conditional swaps).
 __device__ inline bool matrix_inverse5(double* m) {
-  constexpr int N = AGX_NEQ;
+  constexpr int N = AGX_NF;
   double I[AGX_NJ];
 #pragma unroll
   for (int q = 0; q < AGX_NJ; ++q) I[q] = (q / N == q % N) ? 1.0 : 0.0;
@@ -654,27 +657,49 @@ __device__ inline bool matrix_inverse5(double* m) {
 // ArrayMultiplication fluxJacobian.hpp:50-87 (block branch)
 __device__ __forceinline__ void mat_vec5(const double* m, const double* v, double* out) {
 #pragma unroll
-  for (int r = 0; r < AGX_NEQ; ++r) {
+  for (int r = 0; r < AGX_NF; ++r) {
     double a = 0.0;
 #pragma unroll
-    for (int c = 0; c < AGX_NEQ; ++c) a += m[AGX_NEQ * r + c] * v[c];
+    for (int c = 0; c < AGX_NF; ++c) a += m[AGX_NF * r + c] * v[c];
     out[r] = a;
   }
 }
 // RusanovBlockOffDiagonal fluxJacobian.cpp:164-194
+// diagonal turbulence block of the Jacobians (rans + block-matrix solvers):
+// turbModel::InvJac turbulence.cpp:117-160, turbKWSst::ViscJac :772-795
+__device__ __forceinline__ double turb_inv_jac(const double* s, const double* area, bool positive) {
+  const double vn = dot3(s + 1, area);
+  return positive ? 0.5 * (vn * area[3] + fabs(vn) * area[3])
+                  : 0.5 * (vn * area[3] - fabs(vn) * area[3]);
+}
+__device__ __forceinline__ void turb_visc_jac(const GasDev& g, const double* s, const double* area,
+                                              double mu, double dist, double mut, double f1,
+                                              double& jk, double& jw) {
+  const double len = area[3] / dist;
+  jk = g.scaling * len / s[0] * (mu + (f1 * 0.85 + (1.0 - f1) * 1.0) * mut);
+  jw = g.scaling * len / s[0] * (mu + (f1 * 0.5 + (1.0 - f1) * 0.856) * mut);
+}
 __device__ inline void block_off_diagonal(const GasDev& g, bool viscous, const double* s,
                                           const double* du, const double* area, double mu,
                                           double dist, bool positive, const double* vg,
-                                          double* out) {
+                                          double* out, double mut = 0.0, double f1 = 0.0) {
   double J[AGX_NJ];
   rusanov_flux_jacobian(g, s, area, positive, J);
   if (viscous) {
     double V[AGX_NJ];
-    tsl_jacobian(g, s, mu, area, dist, positive, vg, V);
+    tsl_jacobian(g, s, mu, area, dist, positive, vg, V, mut);
 #pragma unroll
     for (int q = 0; q < AGX_NJ; ++q) J[q] = positive ? J[q] - V[q] : J[q] + V[q];
   }
   mat_vec5(J, du, out);
+  if (AGX_NEQ > 5) {
+    // (both signs give InvJac + ViscJac: fac = -1 goes with the subtraction)
+    double jk = 0.0, jw = 0.0;
+    if (viscous) turb_visc_jac(g, s, area, mu, dist, mut, f1, jk, jw);
+    const double tj = turb_inv_jac(s, area, positive);
+    out[AGX_NEQ - 2] = (tj + jk) * du[AGX_NEQ - 2];
+    out[AGX_NEQ - 1] = (tj + jw) * du[AGX_NEQ - 1];
+  }
 }
 
 // ---- ghost states, ghostStates.cpp:62-708 ----------------------------------

@@ -50,6 +50,10 @@ struct BlockDev {
   double* ainv_t;
   double* viscp;
   double* turb3[3];
+  // rans + block-matrix solvers: diagonal of the 2 x 2 turbulence block of a_ / aInv_
+  // (entry e of cell q at [e * nplane + q])
+  double* am_t;
+  double* aminv_t;
   double* wdist;              // wallDist_                procBlock.hpp:88
   D2Dev d2;                   // diagonal-ordered arrays of the LU-SGS path (agx_lusgs.hpp)
   const agx_bc_surface* surf; // boundaryConditions      boundaryConditions.hpp:231
@@ -217,7 +221,7 @@ k_block_diag_inv(BlockDev b, GasDev g, SolverDev sp) {
                     : (RECON == AGX_RECON_MUSCL ? 2 : 3);
   constexpr int NS = 2 * H + 1;
   const long q = b.idx(i, j, k);
-  double D[AGX_NJ];
+  double D[AGX_NJ], dt_ = 0.0;
 #pragma unroll
   for (int e = 0; e < AGX_NJ; ++e) D[e] = 0.0;
   for (int d = 0; d < 3; ++d) {
@@ -238,13 +242,19 @@ k_block_diag_inv(BlockDev b, GasDev g, SolverDev sp) {
     rusanov_flux_jacobian(g, r, al, false, J);
 #pragma unroll
     for (int e = 0; e < AGX_NJ; ++e) D[e] -= J[e];
+    if (AGX_NEQ > 5) dt_ -= turb_inv_jac(r, al, false);
     face_states_1d<RECON, LIM>(sp.kappa, st, w, H + 1, l, r);
     rusanov_flux_jacobian(g, l, au, true, J);
 #pragma unroll
     for (int e = 0; e < AGX_NJ; ++e) D[e] += J[e];
+    if (AGX_NEQ > 5) dt_ += turb_inv_jac(l, au, true);
   }
 #pragma unroll
   for (int e = 0; e < AGX_NJ; ++e) b.am[(long)e * b.nplane + q] = D[e];
+  if (AGX_NEQ > 5) {       // the same number for k and omega (turbModel::InvJac)
+    b.am_t[q] = dt_;
+    b.am_t[b.nplane + q] = dt_;
+  }
 }
 
 template <int RECON, int LIM, int FLUX>
@@ -1493,6 +1503,20 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
       for (int r = 0; r < 3; ++r) { kgc[r] += (1.0 / 6.0) * kg[r]; wgc[r] += (1.0 / 6.0) * wg[r]; }
       mutc += (1.0 / 6.0) * mut; f1c += (1.0 / 6.0) * f1; f2c += (1.0 / 6.0) * f2;
       if (!up) { mut_lo = mut; f1_lo = f1; }
+      if (sp.implicit && sp.block) {
+        // thin-shear-layer Jacobian with the eddy viscosity (flow block) and
+        // turbKWSst::ViscJac (turbulence block): + for both cells of a face
+        // (procBlock.cpp:1417-1424, :1468-1475; fac of fluxJacobian.hpp:749-757)
+        const double v[3] = {b.cen[0][qU] - b.cen[0][qL], b.cen[1][qU] - b.cen[1][qL],
+                             b.cen[2][qU] - b.cen[2][qL]};
+        const double dist = dot3(v, n);
+        double J[AGX_NJ], jk, jw;
+        tsl_jacobian(g, sf, muf, n, dist, up != 0, G, J, mut);
+        for (int e = 0; e < AGX_NJ; ++e) b.am[(long)e * b.nplane + q] += up ? -J[e] : J[e];
+        turb_visc_jac(g, sf, n, muf, dist, mut, f1, jk, jw);
+        b.am_t[q] += jk;
+        b.am_t[b.nplane + q] += jw;
+      }
     }
     // ViscCellSpectralRadius spectralRadius.hpp:94-124 and turbKWSst::
     // ViscousCellSpectralRadius turbulence.cpp:797-815 with the LOWER face's mut, f1
@@ -1532,6 +1556,10 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
     const double src_sr = -2.0 * SST_BETA_STAR * sc[6] * vol * inv_sc;   // SrcSpecRad :739-747
     srt -= src_sr;
     diag_t -= src_sr;
+    if (sp.implicit && sp.block) {     // SubtractFromTurb(TurbSrcJac), turbulence.cpp:749-770
+      b.am_t[q] -= -2.0 * SST_BETA_STAR * sc[6] * 1.0 * vol * inv_sc;
+      b.am_t[b.nplane + q] -= -2.0 * beta * sc[6] * vol * inv_sc;
+    }
   }
   store5(b.resid, q, res);
   b.specrad[q] = sr;
@@ -1540,6 +1568,8 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
   b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (vol / fmax(fmax(sr, srt), 0.0));
   b.turb3[0][q] = mutc; b.turb3[1][q] = f1c; b.turb3[2][q] = f2c;
   b.viscp[q] = muc;       // viscosity_ of this UpdateAuxillaryVariables, read next iteration
+  if (sp.implicit && sp.block)     // velocityGrad_ of the cell, read by the off-diagonal terms
+    for (int e = 0; e < 9; ++e) b.vg[(long)e * b.nplane + q] = vgc[e];
 }
 #endif  // AGX_NEQ == 7
 
@@ -2112,7 +2142,8 @@ __device__ __forceinline__ void add_off_diag(const BlockDev& b, const GasDev& g,
       double vgn[9];
 #pragma unroll
       for (int e = 0; e < 9; ++e) vgn[e] = sp.viscous ? b.vg[(long)e * b.nplane + qn] : 0.0;
-      block_off_diagonal(g, sp.viscous != 0, sn, du, area, mu, dist, lower, vgn, od);
+      block_off_diagonal(g, sp.viscous != 0, sn, du, area, mu, dist, lower, vgn, od,
+                         AGX_NEQ > 5 ? b.turb3[0][qn] : 0.0, AGX_NEQ > 5 ? b.turb3[1][qn] : 0.0);
     } else {
       if (sp.roe_jacobian) load5(b.state, q, sd);
       off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od, sp.roe_jacobian ? sd : nullptr,
@@ -2158,16 +2189,29 @@ k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err) {
 #pragma unroll
     for (int e = 0; e < AGX_NJ; ++e) m[e] = b.am[(long)e * b.nplane + q];
 #pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) m[AGX_NEQ * e + e] = m[AGX_NEQ * e + e] * sp.relax + dvt;
+    for (int e = 0; e < AGX_NF; ++e) m[AGX_NF * e + e] = m[AGX_NF * e + e] * sp.relax + dvt;
 #pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) b.am[(long)(AGX_NEQ * e + e) * b.nplane + q] = m[AGX_NEQ * e + e];
+    for (int e = 0; e < AGX_NF; ++e) b.am[(long)(AGX_NF * e + e) * b.nplane + q] = m[AGX_NF * e + e];
     if (!matrix_inverse5(m)) *err = 3;
 #pragma unroll
     for (int e = 0; e < AGX_NJ; ++e) b.aminv[(long)e * b.nplane + q] = m[e];
+    double it[2] = {0.0, 0.0};
+    if (AGX_NEQ > 5) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const double at = b.am_t[(long)e * b.nplane + q] * sp.relax + dvt;
+        b.am_t[(long)e * b.nplane + q] = at;
+        if (at == 0.0) *err = 3;
+        it[e] = 1.0 / at;
+        b.aminv_t[(long)e * b.nplane + q] = it[e];
+      }
+    }
     if (sp.requires_init) {
       double rb[AGX_NEQ];
       rhs_b(b, g, sp, q, rb);
       mat_vec5(m, rb, x0);
+#pragma unroll
+      for (int e = 5; e < AGX_NEQ; ++e) x0[e] = it[e - 5] * rb[e];
     }
     store5(b.x, q, x0);
     return;
@@ -2187,6 +2231,8 @@ __device__ __forceinline__ void apply_ainv(const BlockDev& b, const SolverDev& s
 #pragma unroll
     for (int e = 0; e < AGX_NJ; ++e) m[e] = b.aminv[(long)e * b.nplane + q];
     mat_vec5(m, v, out);
+#pragma unroll
+    for (int e = 5; e < AGX_NEQ; ++e) out[e] = b.aminv_t[(long)(e - 5) * b.nplane + q] * v[e];
   } else {
     const double ainv = b.ainv[q];
     const double ainv_t = AGX_NEQ > 5 ? b.ainv_t[q] : 0.0;
@@ -2293,6 +2339,8 @@ k_matrix_resid(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
 #pragma unroll
       for (int e = 0; e < AGX_NJ; ++e) m[e] = b.am[(long)e * b.nplane + q];
       mat_vec5(m, xc, ax);
+#pragma unroll
+      for (int e = 5; e < AGX_NEQ; ++e) ax[e] = b.am_t[(long)(e - 5) * b.nplane + q] * xc[e];
     } else {
       const double a = b.a[q];
       const double at = AGX_NEQ > 5 ? b.a_t[q] : 0.0;

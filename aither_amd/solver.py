@@ -279,6 +279,8 @@ class PhasedSolver(Solver):
             if block and cfg.is_viscous:      # gridLevel.cpp:386-388
                 self._halo(abi.HALO_VELGRAD_A)
                 self._halo(abi.HALO_VELGRAD_B)
+            if cfg.n_eq == 7:                 # SwapTurbVars gridLevel.cpp:389-392
+                self._halo(abi.HALO_TURB)
             api.check(api.phase_implicit_begin(ctx), "phase_implicit_begin")
             lusgs = cfg.matrix_solver in (abi.SOLVER["lusgs"], abi.SOLVER["blusgs"])
             for s in range(cfg.matrix_sweeps):

@@ -64,6 +64,7 @@ typedef struct {
   /* rans: turbulence part of specRadius_ / a_ / aInv_ (uncoupledScalar) [cells];
    * (eddyViscosity_, f1_, f2_) interleaved [cells_g][3]; tkeGrad_, omegaGrad_ [cells][3] */
   double *specrad_t, *a_t, *ainv_t, *turb3, *kgrad, *wgrad;
+  double *am_t, *aminv_t; /* block-matrix solvers: diagonal of the turbulence block [cells][2] */
   int nsurf;
   agx_bc_surface *surf;
   int nsurf_i, nsurf_j, nsurf_k;
@@ -1219,10 +1220,11 @@ static void rusanov_flux_jacobian(const ora_ctx *c, const double *s, const doubl
 /* fluxJacobian::ApproxTSLJacobian fluxJacobian.hpp:660-758 with
  * DelprimitiveDelConservative :613-656 and TauNormal utility.cpp:426-436; laminar,
  * one species */
-static void tsl_jacobian(const ora_ctx *c, const double *s, double lamVisc, const double *area,
-                         double dist, int left, const double *vGrad, double *J) {
+static void tsl_jacobian(const ora_ctx *c, const double *s, double lamVisc, double turbVisc,
+                         const double *area, double dist, int left, const double *vGrad,
+                         double *J) {
   const double t = temperature(c, s);
-  const double mu = c->scaling * lamVisc, mut = c->scaling * 0.0;
+  const double mu = c->scaling * lamVisc, mut = c->scaling * turbVisc;
   const double *n = area;
   const double velNorm = dot3(s + 1, n);
   const double rho = s[0];
@@ -1311,6 +1313,18 @@ static void mat_vec(const double *m, const double *v, double *out) {
   }
 }
 
+/* rans with a block-matrix solver: the 2 x 2 turbulence block of every Jacobian is
+ * diagonal -- turbModel::InvJac turbulence.cpp:117-160 (0.5 (conv +- diss), the same
+ * for k and omega), turbKWSst::ViscJac :772-795 (sigma_k / sigma_w), TurbSrcJac
+ * :749-770 -- so it is kept as two numbers per cell, am_t / aminv_t [cells][2] */
+static double turb_inv_jac(const double *s, const double *area, int positive) {
+  const double velNorm = dot3(s + 1, area);
+  return positive ? 0.5 * (velNorm * area[3] + fabs(velNorm) * area[3])
+                  : 0.5 * (velNorm * area[3] - fabs(velNorm) * area[3]);
+}
+static void turb_visc_jac(const ora_ctx *c, const double *s, const double *area, double mu,
+                          double dist, double mut, double f1, double *jk, double *jw);
+
 static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
   const int nn[3] = {b->ni, b->nj, b->nk};
   const int o[3] = {d == 0, d == 1, d == 2};
@@ -1334,6 +1348,10 @@ static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
             double J[NJ];
             rusanov_flux_jacobian(c, fl, area, 1, J);
             for (int q = 0; q < NJ; ++q) b->am[NJ * pl + q] += J[q];
+            if (NEQ > NF) {
+              const double tj = turb_inv_jac(fl, area, 1);
+              b->am_t[2 * pl] += tj; b->am_t[2 * pl + 1] += tj;
+            }
           }
         }
         if (idx[d] < nn[d]) {
@@ -1344,6 +1362,10 @@ static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
             double J[NJ];
             rusanov_flux_jacobian(c, fr, area, 0, J);
             for (int q = 0; q < NJ; ++q) b->am[NJ * p + q] -= J[q];
+            if (NEQ > NF) {
+              const double tj = turb_inv_jac(fr, area, 0);
+              b->am_t[2 * p] -= tj; b->am_t[2 * p + 1] -= tj;
+            }
           }
           const double *au =
               b->fa[d] + 4 * FI(b, d, i + o[0], j + o[1], k + o[2]);
@@ -1621,6 +1643,14 @@ static void visc_flux(const ora_ctx *c, const double *velGrad,
   }
 }
 
+/* turbKWSst::ViscJac turbulence.cpp:772-795 */
+static void turb_visc_jac(const ora_ctx *c, const double *s, const double *area, double mu,
+                          double dist, double mut, double f1, double *jk, double *jw) {
+  const double length = area[3] / dist;
+  *jk = c->scaling * length / s[0] * (mu + sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1) * mut);
+  *jw = c->scaling * length / s[0] * (mu + sst_blend(SST_SIGMA_W1, SST_SIGMA_W2, f1) * mut);
+}
+
 /* procBlock::CalcViscFluxI/J/K procBlock.cpp:1233-2135 (laminar, central) */
 static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
   const int nn[3] = {b->ni, b->nj, b->nk};
@@ -1687,8 +1717,13 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
           }
           if (implicit && is_block(c)) {             /* procBlock.cpp:1417-1424 */
             double J[NJ];
-            tsl_jacobian(c, st, mu, area, proj_c2c(b, d, i, j, k), 1, velGrad, J);
+            tsl_jacobian(c, st, mu, mut, area, proj_c2c(b, d, i, j, k), 1, velGrad, J);
             for (int q = 0; q < NJ; ++q) b->am[NJ * p + q] -= J[q];
+            if (rans) {             /* fac = -1 for the left cell, then Subtract */
+              double jk, jw;
+              turb_visc_jac(c, st, area, mu, proj_c2c(b, d, i, j, k), mut, f1, &jk, &jw);
+              b->am_t[2 * p] -= -1.0 * jk; b->am_t[2 * p + 1] -= -1.0 * jw;
+            }
           }
         }
         if (idx[d] < nn[d]) {
@@ -1721,8 +1756,13 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
           }
           if (implicit && is_block(c)) {             /* procBlock.cpp:1468-1475 */
             double J[NJ];
-            tsl_jacobian(c, st, mu, area, proj_c2c(b, d, i, j, k), 0, velGrad, J);
+            tsl_jacobian(c, st, mu, mut, area, proj_c2c(b, d, i, j, k), 0, velGrad, J);
             for (int q = 0; q < NJ; ++q) b->am[NJ * p + q] += J[q];
+            if (rans) {
+              double jk, jw;
+              turb_visc_jac(c, st, area, mu, proj_c2c(b, d, i, j, k), mut, f1, &jk, &jw);
+              b->am_t[2 * p] += jk; b->am_t[2 * p + 1] += jw;
+            }
           }
         }
       }
@@ -1770,6 +1810,10 @@ static void calc_src_terms(ora_ctx *c, blk_t *b) {
         const double turbSpecRad = -2.0 * SST_BETA_STAR * s[6] * vol * invScaling;
         b->specrad_t[p] -= turbSpecRad;
         if (implicit) b->a_t[p] -= turbSpecRad;
+        if (implicit && is_block(c)) {       /* SubtractFromTurb(TurbSrcJac), :749-770 */
+          b->am_t[2 * p] -= -2.0 * SST_BETA_STAR * s[6] * 1.0 * vol * invScaling;
+          b->am_t[2 * p + 1] -= -2.0 * beta * s[6] * vol * invScaling;
+        }
         b->resid[NEQ * p + 5] -= src5 * vol;
         b->resid[NEQ * p + 6] -= src6 * vol;
       }
@@ -1896,10 +1940,21 @@ static void off_diagonal(const ora_ctx *c, const double *state, const double *di
     rusanov_flux_jacobian(c, state, fArea, positive, J);
     if (c->cfg.is_viscous) {
       double V[NJ];
-      tsl_jacobian(c, state, mu, fArea, dist, positive, vGrad, V);
+      tsl_jacobian(c, state, mu, mut, fArea, dist, positive, vGrad, V);
       for (int q = 0; q < NJ; ++q) J[q] = positive ? J[q] - V[q] : J[q] + V[q];
     }
     mat_vec(J, update, out);
+    if (NEQ > NF) {
+      /* diagonal turbulence block: InvJac -+ fac * ViscJac (fluxJacobian.cpp:183-191,
+       * fluxJacobian.hpp:749-757: fac = -1 when `left` = positive) */
+      double tj = turb_inv_jac(state, fArea, positive), jk = 0.0, jw = 0.0;
+      if (c->cfg.is_viscous) turb_visc_jac(c, state, fArea, mu, dist, mut, f1, &jk, &jw);
+      const double fac = positive ? -1.0 : 1.0;
+      const double dk = positive ? tj - fac * jk : tj + fac * jk;
+      const double dw = positive ? tj - fac * jw : tj + fac * jw;
+      out[5] = dk * update[5];
+      out[6] = dw * update[6];
+    }
     return;
   }
   double su[NEQM], fo[NEQM], fn[NEQM];
@@ -2000,8 +2055,10 @@ static int requires_init(const ora_ctx *c) {
  * linearSolver.cpp:146-175, Invert :177-188; InitializeMatrixUpdate :111-144 */
 /* aInv.ArrayMult(i, j, k, v) (matMultiArray3d.hpp:141-160): scalar or block */
 static void apply_ainv(const ora_ctx *c, const blk_t *b, long p, const double *v, double *out) {
-  if (is_block(c)) mat_vec(b->aminv + NJ * p, v, out);
-  else {
+  if (is_block(c)) {
+    mat_vec(b->aminv + NJ * p, v, out);
+    for (int e = NF; e < NEQ; ++e) out[e] = b->aminv_t[2 * p + e - NF] * v[e];
+  } else {
     for (int e = 0; e < NF; ++e) out[e] = v[e] * b->ainv[p];
     for (int e = NF; e < NEQ; ++e) out[e] = v[e] * b->ainv_t[p];   /* turbulence part */
   }
@@ -2034,6 +2091,12 @@ static int implicit_begin(ora_ctx *c, blk_t *b) {
           }
           memcpy(mi, m, sizeof(double) * NJ);
           if (matrix_inverse(mi, NF)) return 1;
+          for (int e = 0; e < NEQ - NF; ++e) {
+            b->am_t[2 * p + e] *= c->cfg.matrix_relaxation;
+            b->am_t[2 * p + e] += diagVolTime;
+            if (b->am_t[2 * p + e] == 0.0) return fail("Singular matrix in Gauss-Jordan elimination!");
+            b->aminv_t[2 * p + e] = 1.0 / b->am_t[2 * p + e];
+          }
         }
       }
   if (requires_init(c)) {
@@ -2127,8 +2190,10 @@ static void matrix_residual(ora_ctx *c, blk_t *b, double *sumsq, long *size) {
         rhs_b(c, b, i, j, k, rb);
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
         double ax[NEQM];
-        if (is_block(c)) mat_vec(b->am + NJ * p, b->x + NEQ * q, ax);
-        else {
+        if (is_block(c)) {
+          mat_vec(b->am + NJ * p, b->x + NEQ * q, ax);
+          for (int e = NF; e < NEQ; ++e) ax[e] = b->am_t[2 * p + e - NF] * b->x[NEQ * q + e];
+        } else {
           for (int e = 0; e < NF; ++e) ax[e] = b->x[NEQ * q + e] * b->a[p];
           for (int e = NF; e < NEQ; ++e) ax[e] = b->x[NEQ * q + e] * b->a_t[p];
         }
@@ -2160,7 +2225,7 @@ static void free_blk(blk_t *b) {
                      &b->wdist, &b->temp, &b->visc, &b->velgrad, &b->grad18, &b->resid,
                      &b->specrad, &b->dt, &b->consn, &b->consnm1, &b->x,
                      &b->xold, &b->a, &b->ainv, &b->am, &b->aminv, &b->specrad_t,
-                     &b->a_t, &b->ainv_t, &b->turb3, &b->kgrad, &b->wgrad};
+                     &b->a_t, &b->ainv_t, &b->turb3, &b->kgrad, &b->wgrad, &b->am_t, &b->aminv_t};
   for (size_t n = 0; n < sizeof ptrs / sizeof *ptrs; ++n) {
     free(*ptrs[n]);
     *ptrs[n] = NULL;
@@ -2189,7 +2254,7 @@ int ora_debug_jacobian(ora_ctx *c, int which, const double *state, const double 
                        double *out25) {
   if (!c->have_cfg) return fail("config_set first");
   if (which == 0) rusanov_flux_jacobian(c, state, area, flag, out25);
-  else if (which == 1) tsl_jacobian(c, state, mu, area, dist, flag, vgrad_or_mat, out25);
+  else if (which == 1) tsl_jacobian(c, state, mu, 0.0, area, dist, flag, vgrad_or_mat, out25);
   else {
     memcpy(out25, vgrad_or_mat, sizeof(double) * NJ);
     return matrix_inverse(out25, NF);
@@ -2203,10 +2268,8 @@ int ora_config_set(ora_ctx *c, const agx_config *cfg) {
     return fail("n_eq = 7 goes with equation_set rans and nothing else");
   if (cfg->n_eq == 7 && cfg->turbulence_model != AGX_TURB_SST2003)
     return fail("rans: only the sst2003 model is restated");
-  if (cfg->n_eq == 7 && (cfg->matrix_solver == AGX_SOLVER_BLUSGS ||
-                         cfg->matrix_solver == AGX_SOLVER_BDPLUR ||
-                         cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE))
-    return fail("rans: block-matrix solvers and approximateRoe are not restated");
+  if (cfg->n_eq == 7 && cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE)
+    return fail("rans: approximateRoe is not restated");
   if (g_live_cfg > 0 && !c->have_cfg && cfg->n_eq != g_neq)
     return fail("oracle: one equation count per process at a time (%d live)", g_neq);
   if (!c->have_cfg) ++g_live_cfg;
@@ -2277,6 +2340,8 @@ int ora_block_create(ora_ctx *c, const agx_block_geom *g, int *id) {
   b->turb3 = dup_arr(NULL, 3 * b->ncell_g);
   b->kgrad = dup_arr(NULL, 3 * b->ncell);
   b->wgrad = dup_arr(NULL, 3 * b->ncell);
+  b->am_t = dup_arr(NULL, 2 * b->ncell);
+  b->aminv_t = dup_arr(NULL, 2 * b->ncell);
   *id = c->nblk++;
   return 0;
 }
@@ -2477,6 +2542,7 @@ int ora_phase_implicit_update(ora_ctx *c, int mm, double *l2, agx_linf *linf) {
     memset(b->a, 0, sizeof(double) * b->ncell);
     memset(b->a_t, 0, sizeof(double) * b->ncell);
     memset(b->am, 0, sizeof(double) * NJ * b->ncell);
+    memset(b->am_t, 0, sizeof(double) * 2 * b->ncell);
   }
   return 0;
 }

@@ -185,6 +185,26 @@ def test_viscous_block_system_is_consistent(oracle):
     assert res[1] < 1e-6 * res[0], res
 
 
+def test_rans_block_system_is_consistent(oracle):
+    """rans with BLU-SGS (BASELINE configs[4]'s solver): 5 x 5 flow block with eddy
+    viscosity in the thin-shear-layer Jacobian plus the diagonal 2 x 2 turbulence block
+    (InvJac, ViscJac, TurbSrcJac) -- the matrix residual of the 7-equation block system
+    falls by > 10^6 with enough sweeps."""
+    bcs = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristic", 1),
+           4: ("characteristic", 1), 5: ("characteristic", 1), 6: ("characteristic", 1)}
+    kw = dict(n=(8, 8, 6), stretch=1.2, bcs=bcs, equation_set="rans",
+              turbulence_model="sst2003", time_integration="implicitEuler", cfl=10.0,
+              matrix_solver="blusgs")
+    res = []
+    for sweeps in (2, 80):
+        s = Solver(oracle, synthetic.single_block_case(matrix_sweeps=sweeps, **kw))
+        s.step(0)
+        s.step(1)
+        res.append(s.history[-1]["matrix"])
+        s.close()
+    assert res[1] < 1e-6 * res[0], res
+
+
 @pytest.mark.parametrize("solver,sweeps", [("blusgs", 40), ("bdplur", 400)])
 def test_block_solvers_solve_their_linear_system(oracle, solver, sweeps):
     """f - (Ax - b) of the block system (linearSolver::AXmB) falls by many orders

@@ -32,6 +32,11 @@ KW = {
                              2: ("pressureOutlet", 3), 4: ("characteristic", 1)},
                         equation_set="navierStokes", time_integration="implicitEuler",
                         matrix_solver="blusgs", matrix_sweeps=2, cfl=10.0),
+    # rans: eddy viscosity and blending functions cross the ranks after the residual
+    "rans": dict(bcs={3: ("viscousWall", 2), 1: ("characteristic", 1),
+                      2: ("characteristic", 1), 4: ("characteristic", 1)},
+                 equation_set="rans", turbulence_model="sst2003",
+                 time_integration="implicitEuler", matrix_sweeps=2, cfl=10.0),
 }
 
 
@@ -104,7 +109,7 @@ def _run(world, kind, builder, steps=2, in_library=False):
 
 
 @pytest.mark.parametrize("world,kind", [(2, "rk4"), (2, "dplur"), (2, "lusgs"),
-                                        (3, "dplur"), (2, "blusgs_visc")])
+                                        (3, "dplur"), (2, "blusgs_visc"), (2, "rans")])
 def test_phased_multiprocess_matches_single_process(oracle, world, kind):
     res = _run(world, kind, "stacked")
     case = synthetic.stacked_blocks_case((6, 5, 4), nblocks=world, axis="k",
@@ -124,7 +129,7 @@ def test_phased_multiprocess_matches_single_process(oracle, world, kind):
 
 
 @pytest.mark.parametrize("world,kind", [(2, "rk4"), (2, "lusgs"), (3, "dplur"),
-                                        (2, "blusgs_visc")])
+                                        (2, "blusgs_visc"), (2, "rans")])
 def test_iterate_with_exchange_matches_single_process(oracle, world, kind):
     """The in-library multi-rank path: iterate() itself packs, swaps (exchange
     table on gloo, host buffers) and unpacks the slabs of connections to other

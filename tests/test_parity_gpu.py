@@ -622,6 +622,10 @@ RANS_WALL = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristi
     dict(matrix_solver="dplur", matrix_sweeps=3, inviscid_flux="ausm", limiter="minmod"),
     dict(matrix_solver="lusgs", time_integration="bdf2", nonlinear_iterations=2, dt=2.0e-5,
          dual_time_cfl=100.0, face_reconstruction="weno", limiter="none"),
+    # BASELINE configs[4]'s solver: BLU-SGS on the 7-equation set (5 x 5 flow block with
+    # eddy viscosity + diagonal turbulence block); and its point-Jacobi twin
+    dict(matrix_solver="blusgs", matrix_sweeps=2),
+    dict(matrix_solver="bdplur", matrix_sweeps=3, inviscid_flux="ausm"),
 ])
 def test_rans_synthetic_parity(agx_rans, oracle, kw):
     """3-D boxes with a viscous wall: both flux functions, MUSCL and WENO, LU-SGS and
@@ -634,12 +638,14 @@ def test_rans_synthetic_parity(agx_rans, oracle, kw):
 
 
 @pytest.mark.gpu
-def test_rans_stacked_blocks_parity(agx_rans, oracle):
+@pytest.mark.parametrize("solver", ["lusgs", "blusgs"])
+def test_rans_stacked_blocks_parity(agx_rans, oracle, solver):
     """rans across interblock connections: the ghost eddy viscosity and blending
-    function of the off-diagonal terms come from the neighbour block."""
+    function (and, with BLU-SGS, the velocity gradients) of the off-diagonal terms
+    come from the neighbour block -- configs[4] in miniature."""
     case = synthetic.stacked_blocks_case(n=(7, 8, 6), nblocks=2, axis="i", stretch=1.15,
                                          bcs=RANS_WALL, equation_set="rans",
                                          turbulence_model="sst2003",
                                          time_integration="implicitEuler",
-                                         matrix_solver="lusgs", matrix_sweeps=2, cfl=10.0)
+                                         matrix_solver=solver, matrix_sweeps=2, cfl=10.0)
     _close(*run_pair(agx_rans, oracle, case, 2))
