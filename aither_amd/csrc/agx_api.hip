@@ -44,6 +44,8 @@ struct Block {
   double* blockmat = nullptr; // block-matrix solvers: a_ | aInv_ | velocityGrad_ planes
   int* d2_tab = nullptr;      // device: dstart[Pi + Pj] | ij_of_pos[Pi * Pj]
   std::vector<int> dstart;    // host copy (halo index maps)
+  // hyperplane-per-launch sweeps captured as graphs: [forward][both triangles][un_is_u]
+  hipGraphExec_t sweep_graph[2][2][2] = {};
   int* kp_mem = nullptr;      // k_lusgs_kp: progress flag per k-plane | ticket
   int kp_epoch = 0;
   // D2 index of padded cell (i, j, k), host side
@@ -123,6 +125,8 @@ struct agx_ctx {
   int spin_limit = 4000000;  // AGX_SPIN_LIMIT: polls before a waiting plane gives up
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
+  bool use_graphs = true;    // AGX_GRAPHS=0: launch the hyperplane sweeps one by one
+  hipStream_t cap_stream = nullptr;   // stream the sweep graphs are recorded on
   int mresid_split = 1;      // bands of diagonals per XCD in k_matrix_resid_d2 (AGX_MRESID_SPLIT)
   bool have_time_n = false;  // agx_store_time_n has run (nonreflecting BCs read consVarsN)
   // agx_iterate fills the ghost cells for the NEXT call right after the update,
@@ -620,17 +624,38 @@ constexpr int KP_MAX_DIAG = 1 << 30;
 int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full) {
   const BlockDev& b = blk.d;
   if (!b.d2.base) {
+    // One launch per hyperplane i + j + k = p: ni + nj + nk - 2 short launches per half
+    // sweep, bound by launch latency.  The sequence is the same every iteration, so it is
+    // captured once into a hipGraph (per direction / triangle set / value of un_is_u, the
+    // one solver parameter that changes between iterations) and replayed.
     const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
     const int nplanes = b.ni + b.nj + b.nk - 2;
-    for (int t = 0; t < nplanes; ++t) {
-      const int p = forward ? t : nplanes - 1 - t;
-      if (forward)
-        hipLaunchKernelGGL((k_lusgs_plane<true>), grid, tb, 0, c->stream, b, c->gas,
-                           c->sp, p, full);
-      else
-        hipLaunchKernelGGL((k_lusgs_plane<false>), grid, tb, 0, c->stream, b, c->gas,
-                           c->sp, p, full);
+    auto launch_all = [&](hipStream_t st) {
+      for (int t = 0; t < nplanes; ++t) {
+        const int p = forward ? t : nplanes - 1 - t;
+        if (forward)
+          hipLaunchKernelGGL((k_lusgs_plane<true>), grid, tb, 0, st, b, c->gas, c->sp, p, full);
+        else
+          hipLaunchKernelGGL((k_lusgs_plane<false>), grid, tb, 0, st, b, c->gas, c->sp, p, full);
+      }
+    };
+    if (!c->use_graphs || nplanes < 8) {
+      launch_all(c->stream);
+      return 0;
     }
+    hipGraphExec_t& ge = blk.sweep_graph[forward ? 1 : 0][full ? 1 : 0][c->sp.un_is_u ? 1 : 0];
+    if (!ge) {
+      // (recorded on a stream of its own: the library's stream may be the legacy default
+      // stream, which cannot capture; a graph is launched on any stream)
+      if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+      hipGraph_t graph = nullptr;
+      HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+      launch_all(c->cap_stream);
+      HIPCHK(hipStreamEndCapture(c->cap_stream, &graph));
+      HIPCHK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+      HIPCHK(hipGraphDestroy(graph));
+    }
+    HIPCHK(hipGraphLaunch(ge, c->stream));
     return 0;
   }
 #if AGX_FAST
@@ -815,6 +840,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_EAGER_GHOSTS")) c->eager_ghosts = atoi(w) != 0;
     if (const char* w = getenv("AGX_LUSGS")) c->lusgs_mode = !strcmp(w, "plane") ? 0 : 1;
     if (const char* w = getenv("AGX_SPIN_LIMIT")) c->spin_limit = std::max(1, atoi(w));
+    if (const char* w = getenv("AGX_GRAPHS")) c->use_graphs = atoi(w) != 0;
     if (const char* w = getenv("AGX_MRESID_SPLIT")) c->mresid_split = std::min(64, std::max(1, atoi(w)));
   }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
@@ -835,6 +861,8 @@ void agx_ctx_destroy(agx_ctx* c) {
     if (b.blockmat) hipFree(b.blockmat);
     if (b.d2_tab) hipFree(b.d2_tab);
     if (b.kp_mem) hipFree(b.kp_mem);
+    for (auto& g1 : b.sweep_graph) for (auto& g2 : g1) for (auto& g3 : g2)
+      if (g3) hipGraphExecDestroy(g3);
     if (b.surf_dev) hipFree(b.surf_dev);
     if (b.nr_off_dev) hipFree(b.nr_off_dev);
     if (b.nr_mem) hipFree(b.nr_mem);
@@ -865,6 +893,7 @@ void agx_ctx_destroy(agx_ctx* c) {
   if (c->rec_host) hipHostFree(c->rec_host);
   if (c->nccl) ncclCommDestroy(c->nccl);
   for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  if (c->cap_stream) hipStreamDestroy(c->cap_stream);
   delete c;
 }
 
@@ -1051,6 +1080,8 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
 int agx_block_set_bcs(agx_ctx* c, int id, int n, const agx_bc_surface* s) {
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
   Block& b = c->blocks[id];
+  for (auto& g1 : b.sweep_graph) for (auto& g2 : g1) for (auto& g3 : g2)
+    if (g3) { hipGraphExecDestroy(g3); g3 = nullptr; }     // (they hold the old BlockDev)
   b.surf_host.assign(s, s + n);
   if (b.surf_dev) HIPCHK(hipFree(b.surf_dev));
   HIPCHK(hipMalloc((void**)&b.surf_dev, sizeof(agx_bc_surface) * (n > 0 ? n : 1)));

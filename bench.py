@@ -8,7 +8,9 @@ single 256^3 block, WENO5 + AUSMPW+ + viscous fluxes, implicit Euler with one
 scalar LU-SGS sweep, state resident in HBM.  The same line carries, under
 "extra"."rk4", the explicit-RK4 residual sweep (MUSCL thirdOrder + vanAlbada +
 Roe, configs[1] at 256^3) that the north-star ">= 40 % of the HBM roofline"
-clause is stated on.  `--workload rk4|dplur8` make those the headline instead.
+clause is stated on.  `--workload rk4|dplur8|rans4` make those the headline instead
+(rans4: BASELINE configs[4] in kind -- 4 blocks, k-omega SST 2003, BLU-SGS -- on the
+7-equation build of the library).
 
   python bench.py --gpus N --steps K --warmup W
 
@@ -51,6 +53,12 @@ BYTES_DPLUR4_ITER = 1960   # inviscid DPLUR, 4 sweeps
 
 
 def deck_kwargs(workload):
+    if workload == "rans4":
+        # BASELINE configs[4]: turbFlatPlate-style rans, SST 2003, BLU-SGS
+        return dict(equation_set="rans", turbulence_model="sst2003",
+                    face_reconstruction="thirdOrder", limiter="vanAlbada",
+                    inviscid_flux="roe", time_integration="implicitEuler",
+                    matrix_solver="blusgs", matrix_sweeps=1, cfl=50.0)
     if workload == "dplur8":
         return dict(face_reconstruction="thirdOrder", limiter="vanAlbada",
                     inviscid_flux="ausm", time_integration="implicitEuler",
@@ -70,6 +78,16 @@ def rank_local_chain_case(rank, nranks, n, workload, dims=None):
     Only this rank's block is built at full size; its neighbours are built
     four cells thick, which is all the ghost-geometry exchange reads."""
     kw = deck_kwargs(workload)
+    if workload == "rans4":
+        # 4 blocks in a row along the plate (i), wall on j-min, farfield elsewhere;
+        # 4 / nranks blocks per rank
+        bcs = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristic", 1),
+               4: ("characteristic", 1), 5: ("characteristic", 1), 6: ("characteristic", 1)}
+        nb = (n // 2, n // 2, n // 4)
+        case = synthetic.stacked_blocks_case(n=nb, nblocks=4, axis="i", stretch=1.15, bcs=bcs,
+                                             ranks=[b * nranks // 4 for b in range(4)], **kw)
+        case.total_cells = 4 * nb[0] * nb[1] * nb[2]
+        return case
     if workload == "dplur8":
         # BASELINE configs[3]: 2 x 2 x 2 blocks of (n/2)^3 cells, 8 / nranks per rank
         case = synthetic.cube_blocks_case(n=(n // 2,) * 3, splits=(2, 2, 2),
@@ -165,17 +183,19 @@ def cpu_baseline(workload, budget_s=12.0):
     s.store_time_n(0)
     s.iterate(0, 0.5)                      # warm-up
     its, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
+    # (the perturbed synthetic rans start is only followed for a few iterations)
+    max_its = 6 if workload == "rans4" else 1 << 30
+    while time.perf_counter() - t0 < budget_s and its < max_its:
         if its % nonlin == 0:
             s.store_time_n(its // nonlin)
         s.iterate(its % nonlin, case.deck.cfl(0))
         its += 1
     dt = time.perf_counter() - t0
     s.close()
-    out = dict(value=n ** 3 * its / dt / 1e6, unit="Mcell-updates/s", cores=1,
+    out = dict(value=case.total_cells * its / dt / 1e6, unit="Mcell-updates/s", cores=1,
                kind="port",
-               sample=f"{its} iterations of the same scheme on a {n}^3 block "
-                      f"({dt:.1f} s, oracle/liboracle.so, gcc -O2, 1 thread)")
+               sample=f"{its} iterations of the same scheme on {case.total_cells} cells "
+                      f"(size parameter {n}; {dt:.1f} s, oracle/liboracle.so, gcc -O2, 1 thread)")
     if workload in REFERENCE_SURVEY:
         out["reference_survey"] = REFERENCE_SURVEY[workload]
     return out
@@ -190,6 +210,15 @@ LUSGS_PASSES = [
     ("F+B  LU-SGS forward + backward sweep (k_lusgs_kp x 2)", 344 + 248, (3,)),
     ("M  matrix residual (k_matrix_resid_d2)", 280, (6,)),
     ("U  update + norms (k_update_d2, k_norm_final)", 160, (1,)),
+]
+# rans on the one-thread-per-cell kernels: no per-pass byte model is claimed (the
+# kernels gather their stencils; bytes_per_cell = the 7-equation analogue of SURVEY 8d)
+RANS_PASSES = [
+    ("R  residual + sources + dt + block diagonal (k_inv_residual, k_block_diag_inv, "
+     "k_visc_residual_rans)", 8 * (7 + 19 + 7 + 3 + 29), (0, 4, 5)),
+    ("F+B  BLU-SGS hyperplane sweeps (k_lusgs_plane)", 2 * 8 * (7 * 7 + 19 + 29 + 7), (3,)),
+    ("M  matrix residual", 8 * (7 * 7 + 19 + 29), (6,)),
+    ("U  update + norms", 8 * (3 * 7), (1,)),
 ]
 DPLUR_PASSES = [
     ("R  residual + dt + diagonal", 240, (0, 4, 5)),
@@ -206,6 +235,11 @@ WORKLOAD_TEXT = {
               "single {n}^3 block per GPU, single-species air, WENO5 + AUSMPW+ inviscid + "
               "viscous fluxes, implicit Euler, scalar LU-SGS 1 sweep, viscous wall + "
               "characteristic",
+              "one nonlinear iteration (mgSolution::Iterate)"),
+    "rans4": ("residual+BLU-SGS, rans SST 2003",
+              "4 blocks of {h}x{h}x{q} cells in a row shared by the GPUs, k-omega SST 2003 "
+              "(7 equations), MUSCL thirdOrder + vanAlbada + Roe, viscous wall, implicit "
+              "Euler, BLU-SGS 1 sweep (one-thread-per-cell kernels, libaither_gfx950_rans.so)",
               "one nonlinear iteration (mgSolution::Iterate)"),
     "dplur8": ("residual + DPLUR",
                "2x2x2 blocks of {h}^3 cells shared by the GPUs, Euler MUSCL + AUSMPW+, "
@@ -302,6 +336,9 @@ def run_workload(args, workload, api, world, rank, local_rank):
     if workload == "dplur8":      # strong scaling: the 8 blocks are divided
         total_cells = 8 * (n // 2) ** 3
         cells_rank = total_cells // world
+    if workload == "rans4":
+        total_cells = case.total_cells
+        cells_rank = total_cells // world
     return dict(workload=workload, n=n, elapsed=elapsed, groups=groups,
                 cells_rank=cells_rank, total_cells=total_cells, transport=transport)
 
@@ -348,7 +385,8 @@ def build_line(args, res, world):
                                frac=BYTES_STAGE * cells_rank /
                                (stage_ms * 1e-3) / HBM_PEAK))
     else:
-        passes = LUSGS_PASSES if workload == "lusgs" else DPLUR_PASSES
+        passes = (LUSGS_PASSES if workload == "lusgs" else
+                  RANS_PASSES if workload == "rans4" else DPLUR_PASSES)
         kern, dev_ms = [], 0.0
         for name, bpc, gs in passes:
             ms = sum(groups[g][0] * groups[g][1] for g in gs) / max(steps, 1)
@@ -382,11 +420,11 @@ def build_line(args, res, world):
         "steps": steps, "warmup": args.warmup,
         "ms_per_step": res["elapsed"] / steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong" if workload == "dplur8" else "weak",
+        "scaling": "strong" if workload in ("dplur8", "rans4") else "weak",
         "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": wl.format(n=n, h=n // 2), "iteration": itn,
-                   "blocks": 8 if workload == "dplur8" else world,
+        "config": {"workload": wl.format(n=n, h=n // 2, q=n // 4), "iteration": itn,
+                   "blocks": 8 if workload == "dplur8" else 4 if workload == "rans4" else world,
                    "cells_per_gpu": cells_rank,
                    "halo": ("none" if world == 1 else
                             "RCCL grouped send/recv + all-gather of the norms on the "
@@ -402,7 +440,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--workload", choices=["rk4", "lusgs", "dplur8"], default="lusgs")
+    ap.add_argument("--workload", choices=["rk4", "lusgs", "dplur8", "rans4"], default="lusgs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extra.rk4 measurement of the default line")
@@ -431,7 +469,7 @@ def main():
     elif world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    api = aither_amd.load()
+    api = aither_amd.load(7 if args.workload == "rans4" else 5)
     res = run_workload(args, args.workload, api, world, rank, local_rank)
     extra = None
     if args.workload == "lusgs" and world == 1 and not args.no_extra and not args.dims:

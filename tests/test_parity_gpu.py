@@ -649,3 +649,15 @@ def test_rans_stacked_blocks_parity(agx_rans, oracle, solver):
                                          time_integration="implicitEuler",
                                          matrix_solver=solver, matrix_sweeps=2, cfl=10.0)
     _close(*run_pair(agx_rans, oracle, case, 2))
+
+
+@pytest.mark.gpu
+def test_rans4_config_parity(agx_rans, oracle):
+    """BASELINE configs[4] in kind and in small: four blocks in a row, k-omega SST 2003,
+    BLU-SGS, viscous wall (the case `bench.py --workload rans4` times)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    case = bench.rank_local_chain_case(0, 1, 24, "rans4")
+    assert case.n_eq == 7 and len(case.blocks) == 4
+    _close(*run_pair(agx_rans, oracle, case, 2))
