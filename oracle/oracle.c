@@ -531,9 +531,10 @@ static double inv_cell_spec_rad(const ora_ctx *c, const double *s,
   const double fMag = 0.5 * (al[3] + au[3]);
   return (fabs(dot3(s + 1, nv)) + sos(c, s)) * fMag;
 }
+static double turb_prandtl(const ora_ctx *c);
 /* ViscCellSpectralRadius spectralRadius.hpp:94-124 */
 static double visc_term_t(const ora_ctx *c, double mu, double mut) {
-  return c->scaling * (mu / c->prandtl + mut / 0.9);
+  return c->scaling * (mu / c->prandtl + mut / turb_prandtl(c));
 }
 static double visc_cell_spec_rad(const ora_ctx *c, const double *s,
                                  const double *al, const double *au,
@@ -635,9 +636,10 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
                           const agx_bc_state *d, int layer, double wallDist, double nuW,
                           const nr_data *nr, double *ghost) {
   const int rans = NEQ > NF;
-  if (rans && bc != AGX_BC_SLIPWALL && bc != AGX_BC_VISCOUSWALL && bc != AGX_BC_CHARACTERISTIC)
+  if (rans && bc != AGX_BC_SLIPWALL && bc != AGX_BC_VISCOUSWALL && bc != AGX_BC_CHARACTERISTIC &&
+      bc != AGX_BC_STAGNATION_INLET && bc != AGX_BC_PRESSURE_OUTLET)
     return fail("rans: boundary type %d is not restated (slipWall, viscousWall, "
-                "characteristic, interblock, periodic are)", bc);
+                "characteristic, stagnationInlet, pressureOutlet, interblock, periodic are)", bc);
   for (int e = 0; e < NEQ; ++e) ghost[e] = interior[e];
   const int isLower = surf % 2 == 1;
   double n[3];
@@ -668,7 +670,8 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
       /* low-Re wall, ghostStates.cpp:261-279: k = 0 at the face, omega of Menter's
        * wall value (WallBeta = beta1, turbulence.hpp:577) */
       ghost[5] = -1.0 * interior[5];
-      const double wWall = c->scaling * c->scaling * 60.0 * nuW / (wallDist * wallDist * 0.075);
+      const double wallBeta = c->cfg.turbulence_model == AGX_TURB_KW_WILCOX2006 ? 0.0708 : 0.075;
+      const double wWall = c->scaling * c->scaling * 60.0 * nuW / (wallDist * wallDist * wallBeta);
       ghost[6] = 2.0 * wWall - interior[6];
       if (layer > 1) ghost[6] = layer * ghost[6] - wWall;
     }
@@ -794,12 +797,15 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
     ghost[2] = vbMag * d->direction[1];
     ghost[3] = vbMag * d->direction[2];
     ghost[4] = pb;
+    /* farfield turbulence from the ghost velocity, ghostStates.cpp:581-585, :593-598 */
+    if (rans) apply_farfield_turb(c, ghost, ghost + 1, d->turb_intensity, d->eddy_visc_ratio);
     double tmp[NEQM];
     extrap_hold(ghost, 2.0, interior, tmp);
     memcpy(ghost, tmp, sizeof(double) * NEQ);
     if (layer > 1) {
       extrap_hold(ghost, (double)layer, interior, tmp);
       memcpy(ghost, tmp, sizeof(double) * NEQ);
+      if (rans) apply_farfield_turb(c, ghost, ghost + 1, d->turb_intensity, d->eddy_visc_ratio);
     }
   } else if (bc == AGX_BC_PRESSURE_OUTLET) {
     if (d->is_nonreflecting && !nr)
@@ -1608,6 +1614,68 @@ static void sst_eddy_visc_blending(const ora_ctx *c, const double *s, const doub
   *mut = s[0] * SST_A1 * s[5] / (d1 > d2 ? d1 : d2);
 }
 
+/* k-omega Wilcox 2006, turbulence.hpp:390-470 / turbulence.cpp:266-560 */
+#define KW_GAMMA 0.52
+#define KW_BETA_STAR 0.09
+#define KW_SIGMA 0.5
+#define KW_SIGMA_STAR 0.6
+#define KW_SIGMA_D0 0.125
+#define KW_BETA0 0.0708
+#define KW_CLIM 0.875
+static int is_wilcox(const ora_ctx *c) { return c->cfg.turbulence_model == AGX_TURB_KW_WILCOX2006; }
+/* TurbPrandtlNumber: 8/9 (Wilcox), 0.9 (SST) */
+static double turb_prandtl(const ora_ctx *c) { return is_wilcox(c) ? 8.0 / 9.0 : 0.9; }
+static double sigma_k(const ora_ctx *c, double f1) {
+  return is_wilcox(c) ? KW_SIGMA_STAR : sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1);
+}
+static double sigma_w(const ora_ctx *c, double f1) {
+  return is_wilcox(c) ? KW_SIGMA : sst_blend(SST_SIGMA_W1, SST_SIGMA_W2, f1);
+}
+/* the eddy viscosity of the k / omega diffusion and of the turbulence spectral radii:
+ * the limited one (SST) or EddyViscosityNoLim = rho k / omega (Wilcox,
+ * UseUnlimitedEddyVisc turbulence.hpp:439, turbulence.cpp:495-548) */
+static double turb_diff_visc(const ora_ctx *c, const double *s, double mut) {
+  return is_wilcox(c) ? s[0] * s[5] / s[6] : mut;
+}
+/* turbKWWilcox::EddyViscAndBlending turbulence.cpp:412-430 with OmegaTilda :339-351 */
+static void kw_eddy_visc_blending(const ora_ctx *c, const double *s, const double *velGrad,
+                                  double *mut, double *f1, double *f2) {
+  const double trace = velGrad[0] + velGrad[4] + velGrad[8];
+  double ss = 0.0;
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) {
+      const double id = r == q ? 1.0 : 0.0;
+      const double a = 0.5 * (velGrad[3 * r + q] + velGrad[3 * q + r]) - 1.0 / 3.0 * trace * id;
+      const double bq = 0.5 * (velGrad[3 * q + r] + velGrad[3 * r + q]) - 1.0 / 3.0 * trace * id;
+      ss += a * bq;
+    }
+  const double lim = c->scaling * KW_CLIM * sqrt(2.0 * ss / KW_BETA_STAR);
+  const double omegaTilda = s[6] > lim ? s[6] : lim;
+  *f1 = 1.0;
+  *f2 = 0.0;
+  *mut = s[0] * s[5] / omegaTilda;
+}
+/* turbKWWilcox::Beta / FBeta / Xw / StrainKI turbulence.cpp:291-337 */
+static double kw_beta(const ora_ctx *c, const double *s, const double *vg) {
+  double W[9], K[9], WW[9];
+  const double trace = vg[0] + vg[4] + vg[8];
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) {
+      W[3 * r + q] = 0.5 * (vg[3 * r + q] - vg[3 * q + r]);
+      K[3 * r + q] = 0.5 * (vg[3 * r + q] + vg[3 * q + r] - trace * (r == q ? 1.0 : 0.0));
+    }
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) {
+      WW[3 * r + q] = 0.0;
+      for (int m = 0; m < 3; ++m) WW[3 * r + q] += W[3 * r + m] * W[3 * m + q];
+    }
+  double ddot = 0.0;                       /* DoubleDotTrans: sum_ij A_ij B_ji */
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) ddot += WW[3 * r + q] * K[3 * q + r];
+  const double xw = fabs(ddot / pow(KW_BETA_STAR * s[6], 3.0)) * pow(c->scaling, 3.0);
+  return KW_BETA0 * ((1.0 + 85.0 * xw) / (1.0 + 100.0 * xw));
+}
+
 /* viscousFlux::CalcFlux viscousFlux.cpp:58-135 (one species; turbVisc = 0 and no
  * turbulence entries in laminar runs) */
 static void visc_flux(const ora_ctx *c, const double *velGrad,
@@ -1633,13 +1701,15 @@ static void visc_flux(const ora_ctx *c, const double *velGrad,
   f[3] = tau[2];
   const double t = temperature(c, s);
   const double kk = conductivity(c, t) * c->scaling;
-  const double kt = mut * c->cp / 0.9;
+  const double kt = mut * c->cp / turb_prandtl(c);
   f[4] = dot3(tau, s + 1) + (kk + kt) * dot3(tGrad, n) + 0.0;
   if (NEQ > NF) {
-    const double tkeCoeff = sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1);
-    const double omgCoeff = sst_blend(SST_SIGMA_W1, SST_SIGMA_W2, f1);
-    f[5] = (mu + tkeCoeff * mut) * dot3(kGrad, n);
-    f[6] = (mu + omgCoeff * mut) * dot3(wGrad, n);
+    const double tkeCoeff = sigma_k(c, f1);
+    const double omgCoeff = sigma_w(c, f1);
+    /* UseUnlimitedEddyVisc (Wilcox): NondimScaling * EddyViscNoLim(state) */
+    const double mutt = is_wilcox(c) ? c->scaling * (s[0] * s[5] / s[6]) : mut;
+    f[5] = (mu + tkeCoeff * mutt) * dot3(kGrad, n);
+    f[6] = (mu + omgCoeff * mutt) * dot3(wGrad, n);
   }
 }
 
@@ -1647,8 +1717,8 @@ static void visc_flux(const ora_ctx *c, const double *velGrad,
 static void turb_visc_jac(const ora_ctx *c, const double *s, const double *area, double mu,
                           double dist, double mut, double f1, double *jk, double *jw) {
   const double length = area[3] / dist;
-  *jk = c->scaling * length / s[0] * (mu + sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1) * mut);
-  *jw = c->scaling * length / s[0] * (mu + sst_blend(SST_SIGMA_W1, SST_SIGMA_W2, f1) * mut);
+  *jk = c->scaling * length / s[0] * (mu + sigma_k(c, f1) * turb_diff_visc(c, s, mut));
+  *jw = c->scaling * length / s[0] * (mu + sigma_w(c, f1) * turb_diff_visc(c, s, mut));
 }
 
 /* procBlock::CalcViscFluxI/J/K procBlock.cpp:1233-2135 (laminar, central) */
@@ -1698,7 +1768,8 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
           central_coeffs(b->wid[d][cL], b->wid[d][cU], cf);
           double wDist = cf[0] * b->wdist[cU] + cf[1] * b->wdist[cL];
           if (wDist < 0.0 && wDist > -1.0e-10) wDist = 0.0;      /* WALL_DIST_NEG_TOL */
-          sst_eddy_visc_blending(c, st, velGrad, kGrad, wGrad, mu, wDist, &mut, &f1, &f2);
+          if (is_wilcox(c)) kw_eddy_visc_blending(c, st, velGrad, &mut, &f1, &f2);
+          else sst_eddy_visc_blending(c, st, velGrad, kGrad, wGrad, mu, wDist, &mut, &f1, &f2);
         }
         visc_flux(c, velGrad, tGrad, area, st, mu, mut, f1, kGrad, wGrad, f);
         const int idx[3] = {i, j, k};
@@ -1750,7 +1821,8 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
              * face's mut and f1 (procBlock.cpp:1459-1466) */
             const double fMag = 0.5 * (area[3] + au[3]);
             const double tvsr = c->scaling * (fMag * fMag / b->vol[cU]) / b->state[NEQ * cU] *
-                                (b->visc[cU] + sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1) * mut);
+                                (b->visc[cU] + sigma_k(c, f1) *
+                                 turb_diff_visc(c, b->state + NEQ * cU, mut));
             b->specrad_t[p] += tvsr * viscCoeff;
             if (implicit) b->a_t[p] += 2.0 * tvsr;
           }
@@ -1783,11 +1855,6 @@ static void calc_src_terms(ora_ctx *c, blk_t *b) {
         const double *kg = b->kgrad + 3 * p, *wg = b->wgrad + 3 * p;
         const double mut = b->turb3[3 * q], f1 = b->turb3[3 * q + 1];
         const double vol = b->vol[q];
-        const double cdkw = sst_cdkw(s, kg, wg);
-        const double gamma = sst_blend(SST_GAMMA1, SST_GAMMA2, f1);
-        const double beta = sst_blend(SST_BETA1, SST_BETA2, f1);
-        const double tkeDest = invScaling * SST_BETA_STAR * (s[0] * s[5] * s[6] * 1.0);
-        const double omgDest = invScaling * beta * (s[0] * s[6] * s[6]);
         /* BoussinesqReynoldsStress turbulence.cpp:57-69, DoubleDotTrans with velGrad */
         const double lambda = 0.0 - (2.0 / 3.0) * mut;
         const double trace = vg[0] + vg[4] + vg[8];
@@ -1799,13 +1866,34 @@ static void calc_src_terms(ora_ctx *c, blk_t *b) {
                                2.0 / 3.0 * s[0] * s[5] * id;
             ddot += tau * vg[3 * cc + r];
           }
-        double tkeProd = c->scaling * ddot;
-        if (SST_KPROD2DEST * tkeDest < tkeProd) tkeProd = SST_KPROD2DEST * tkeDest;
-        if (tkeProd < 0.0) tkeProd = 0.0;
-        double omgProd = gamma * s[0] / mut * tkeProd;
-        if (omgProd < 0.0) omgProd = 0.0;
-        const double omgCd = c->scaling * (1.0 - f1) * cdkw;
-        const double src5 = tkeProd - tkeDest, src6 = omgProd - omgDest + omgCd;
+        const double tkeDest = invScaling * SST_BETA_STAR * (s[0] * s[5] * s[6] * 1.0);
+        double beta, src5, src6;
+        if (is_wilcox(c)) {
+          /* turbKWWilcox::CalcTurbSrc turbulence.cpp:359-407 */
+          beta = kw_beta(c, s, vg);
+          const double omgDest = invScaling * beta * (s[0] * s[6] * s[6]);
+          double tkeProd = c->scaling * ddot;
+          if (tkeProd < 0.0) tkeProd = 0.0;
+          double omgProd = KW_GAMMA * s[6] / s[5] * tkeProd;
+          if (omgProd < 0.0) omgProd = 0.0;
+          const double kw = dot3(kg, wg);
+          const double omgCd = c->scaling * (kw <= 0.0 ? 0.0 : KW_SIGMA_D0) * (s[0] / s[6] * kw);
+          src5 = tkeProd - tkeDest;
+          src6 = omgProd - omgDest + omgCd;
+        } else {
+          const double cdkw = sst_cdkw(s, kg, wg);
+          const double gamma = sst_blend(SST_GAMMA1, SST_GAMMA2, f1);
+          beta = sst_blend(SST_BETA1, SST_BETA2, f1);
+          const double omgDest = invScaling * beta * (s[0] * s[6] * s[6]);
+          double tkeProd = c->scaling * ddot;
+          if (SST_KPROD2DEST * tkeDest < tkeProd) tkeProd = SST_KPROD2DEST * tkeDest;
+          if (tkeProd < 0.0) tkeProd = 0.0;
+          double omgProd = gamma * s[0] / mut * tkeProd;
+          if (omgProd < 0.0) omgProd = 0.0;
+          const double omgCd = c->scaling * (1.0 - f1) * cdkw;
+          src5 = tkeProd - tkeDest;
+          src6 = omgProd - omgDest + omgCd;
+        }
         /* turbKWSst::SrcSpecRad turbulence.cpp:739-747 */
         const double turbSpecRad = -2.0 * SST_BETA_STAR * s[6] * vol * invScaling;
         b->specrad_t[p] -= turbSpecRad;
@@ -1991,7 +2079,7 @@ static void off_diagonal(const ora_ctx *c, const double *state, const double *di
     double tsr = positive ? 0.5 * fArea[3] * fabs(velNorm + fabs(velNorm))
                           : 0.5 * fArea[3] * fabs(velNorm - fabs(velNorm));
     tsr += c->scaling * (fArea[3] / dist) / state[0] *
-           (mu + sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1) * mut);
+           (mu + sigma_k(c, f1) * turb_diff_visc(c, state, mut));
     for (int e = NF; e < NEQ; ++e) {
       const double fc = 0.0;
       out[e] = positive ? fc + update[e] * tsr : fc - update[e] * tsr;
@@ -2266,8 +2354,9 @@ int ora_config_set(ora_ctx *c, const agx_config *cfg) {
   if (cfg->n_eq != 5 && cfg->n_eq != 7) return fail("n_eq is 5, or 7 for rans");
   if ((cfg->n_eq == 7) != (cfg->equation_set == AGX_EQN_RANS))
     return fail("n_eq = 7 goes with equation_set rans and nothing else");
-  if (cfg->n_eq == 7 && cfg->turbulence_model != AGX_TURB_SST2003)
-    return fail("rans: only the sst2003 model is restated");
+  if (cfg->n_eq == 7 && cfg->turbulence_model != AGX_TURB_SST2003 &&
+      cfg->turbulence_model != AGX_TURB_KW_WILCOX2006)
+    return fail("rans: the sst2003 and kOmegaWilcox2006 models are restated");
   if (cfg->n_eq == 7 && cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE)
     return fail("rans: approximateRoe is not restated");
   if (g_live_cfg > 0 && !c->have_cfg && cfg->n_eq != g_neq)
