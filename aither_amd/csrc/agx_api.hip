@@ -913,8 +913,9 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
 #if AGX_NEQ == 7
   if (cfg->equation_set != AGX_EQN_RANS || !cfg->is_viscous)
     return fail("the 7-equation library serves equation_set rans (viscous) only");
-  if (cfg->turbulence_model != AGX_TURB_SST2003)
-    return fail("turbulence_model %d: only sst2003 is built", cfg->turbulence_model);
+  if (cfg->turbulence_model != AGX_TURB_SST2003 && cfg->turbulence_model != AGX_TURB_KW_WILCOX2006)
+    return fail("turbulence_model %d: sst2003 and kOmegaWilcox2006 are built",
+                cfg->turbulence_model);
   if (cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE)
     return fail("rans: approximateRoe is not built");
 #else
@@ -949,6 +950,8 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
     return fail("block-matrix solvers are built for inviscidFluxJacobian rusanov only");
   c->cfg = *cfg;
   derive_gas(*cfg, c->gas);
+  c->gas.wilcox = cfg->turbulence_model == AGX_TURB_KW_WILCOX2006 ? 1 : 0;
+  c->gas.turb_prandtl = c->gas.wilcox ? 8.0 / 9.0 : 0.9;
   SolverDev& sp = c->sp;
   sp.kappa = cfg->kappa;
   sp.theta = cfg->theta;

@@ -32,6 +32,10 @@ struct GasDev {
   double scaling;   // transport::NondimScaling  transport.hpp:43-46
   double inv_n;     // 1 / n
   double inv_prandtl;
+  // rans: turbulence model (0: k-omega SST 2003, 1: k-omega Wilcox 2006) and its
+  // turbulent Prandtl number (0.9 / 8/9; turbulence.hpp:500, :398)
+  int wilcox;
+  double turb_prandtl;
 };
 
 struct Prim {  // primitive: rho, u, v, w, p  (varArray.hpp:40-51)
@@ -445,6 +449,19 @@ __device__ __forceinline__ double visc_term(const GasDev& g, double mu) {
   return g.scaling * (mu * g.inv_prandtl);
 }
 
+// sigma_k / sigma_w of the k / omega diffusion (SST: blended; Wilcox: sigmaStar, sigma) and
+// the eddy viscosity of that diffusion and of the turbulence spectral radii: the limited
+// one (SST) or EddyViscosityNoLim = rho k / omega (Wilcox, UseUnlimitedEddyVisc)
+__device__ __forceinline__ double turb_sigma_k(const GasDev& g, double f1) {
+  return g.wilcox ? 0.6 : f1 * 0.85 + (1.0 - f1) * 1.0;
+}
+__device__ __forceinline__ double turb_sigma_w(const GasDev& g, double f1) {
+  return g.wilcox ? 0.5 : f1 * 0.5 + (1.0 - f1) * 0.856;
+}
+__device__ __forceinline__ double turb_diff_visc(const GasDev& g, const double* s, double mut) {
+  return (AGX_NEQ > 5 && g.wilcox) ? s[0] * s[AGX_NEQ - 2] / s[AGX_NEQ - 1] : mut;
+}
+
 // RusanovScalarOffDiagonal fluxJacobian.cpp:122-162 with FaceSpectralRadius
 // spectralRadius.hpp:182-203 and ConvectiveFluxUpdate inviscidFlux.hpp:544-562
 // diag != nullptr selects RoeOffDiagonal (fluxJacobian.cpp:240-291, inviscid): the
@@ -470,7 +487,7 @@ __device__ __forceinline__ void off_diagonal(const GasDev& g, bool viscous,
   double sr = 0.5 * area[3] * (fabs(dot3(s + 1, area)) + sound_speed(g, s));
   if (viscous)
     sr += area[3] * fast_rcp(dist) * visc_max_term(g, s[0]) *
-          (AGX_NEQ > 5 ? g.scaling * (mu * g.inv_prandtl + mut / 0.9) : visc_term(g, mu));
+          (AGX_NEQ > 5 ? g.scaling * (mu * g.inv_prandtl + mut / g.turb_prandtl) : visc_term(g, mu));
   const double sg = positive ? 1.0 : -1.0;
 #pragma unroll
   for (int e = 0; e < 5; ++e)
@@ -481,7 +498,8 @@ __device__ __forceinline__ void off_diagonal(const GasDev& g, bool viscous,
     // (turbulence.cpp:174-186) + turbKWSst::ViscousFaceSpectralRadius (:817-831)
     const double vn = dot3(s + 1, area);
     double tsr = positive ? 0.5 * area[3] * fabs(vn + fabs(vn)) : 0.5 * area[3] * fabs(vn - fabs(vn));
-    tsr += g.scaling * (area[3] / dist) / s[0] * (mu + (f1 * 0.85 + (1.0 - f1) * 1.0) * mut);
+    tsr += g.scaling * (area[3] / dist) / s[0] *
+           (mu + turb_sigma_k(g, f1) * turb_diff_visc(g, s, mut));
 #pragma unroll
     for (int e = 5; e < AGX_NEQ; ++e) out[e] = sg * du[e] * tsr;
   }
@@ -546,7 +564,8 @@ __device__ inline void tsl_jacobian(const GasDev& g, const double* s, double lam
   const double* n = area;
   const double vn = dot3(s + 1, n);
   const double rho = s[0];
-  const double k = conductivity(g, t) * g.scaling + mut * g.cp / 0.9;
+  const double k = conductivity(g, t) * g.scaling +
+                   (AGX_NEQ > 5 ? mut * g.cp / g.turb_prandtl : 0.0);
   const double lambda = 0.0 - (2.0 / 3.0) * mu;
   const double trace = vg[0] + vg[4] + vg[8];
   double tau[3];
@@ -676,8 +695,8 @@ __device__ __forceinline__ void turb_visc_jac(const GasDev& g, const double* s, 
                                               double mu, double dist, double mut, double f1,
                                               double& jk, double& jw) {
   const double len = area[3] / dist;
-  jk = g.scaling * len / s[0] * (mu + (f1 * 0.85 + (1.0 - f1) * 1.0) * mut);
-  jw = g.scaling * len / s[0] * (mu + (f1 * 0.5 + (1.0 - f1) * 0.856) * mut);
+  jk = g.scaling * len / s[0] * (mu + turb_sigma_k(g, f1) * turb_diff_visc(g, s, mut));
+  jw = g.scaling * len / s[0] * (mu + turb_sigma_w(g, f1) * turb_diff_visc(g, s, mut));
 }
 __device__ inline void block_off_diagonal(const GasDev& g, bool viscous, const double* s,
                                           const double* du, const double* area, double mu,
@@ -746,7 +765,8 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
                                    const NrDev* nr = nullptr, double nu_w = 0.0) {
   // rans: the other boundary types are not built (as in the oracle)
   if (AGX_NEQ > 5 && bc != AGX_BC_SLIPWALL && bc != AGX_BC_VISCOUSWALL &&
-      bc != AGX_BC_CHARACTERISTIC)
+      bc != AGX_BC_CHARACTERISTIC && bc != AGX_BC_STAGNATION_INLET &&
+      bc != AGX_BC_PRESSURE_OUTLET)
     return false;
 #pragma unroll
   for (int e = 0; e < AGX_NEQ; ++e) gh[e] = in[e];
@@ -774,7 +794,9 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
         // low-Re wall, ghostStates.cpp:261-279: k = 0 at the face, Menter's wall omega
         // (WallBeta = beta1 = 0.075)
         gh[AGX_NEQ - 2] = -1.0 * in[AGX_NEQ - 2];
-        const double w_wall = g.scaling * g.scaling * 60.0 * nu_w / (wall_dist * wall_dist * 0.075);
+        // (WallBeta: beta1 of SST, beta0 of Wilcox 2006)
+        const double w_wall = g.scaling * g.scaling * 60.0 * nu_w /
+                              (wall_dist * wall_dist * (g.wilcox ? 0.0708 : 0.075));
         gh[AGX_NEQ - 1] = 2.0 * w_wall - in[AGX_NEQ - 1];
         if (layer > 1) gh[AGX_NEQ - 1] = layer * gh[AGX_NEQ - 1] - w_wall;
       }
@@ -866,12 +888,15 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
       gh[2] = vb * d.direction[1];
       gh[3] = vb * d.direction[2];
       gh[4] = pb;
+      // farfield turbulence from the ghost velocity, ghostStates.cpp:581-585, :593-598
+      apply_farfield_turb(g, gh, gh + 1, d.turb_intensity, d.eddy_visc_ratio);
       double t[AGX_NEQ];
       extrap_hold(gh, 2.0, in, t);
       for (int e = 0; e < AGX_NEQ; ++e) gh[e] = t[e];
       if (layer > 1) {
         extrap_hold(gh, (double)layer, in, t);
         for (int e = 0; e < AGX_NEQ; ++e) gh[e] = t[e];
+        apply_farfield_turb(g, gh, gh + 1, d.turb_intensity, d.eddy_visc_ratio);
       }
       return true;
     }

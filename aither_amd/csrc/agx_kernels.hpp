@@ -1402,6 +1402,48 @@ __device__ inline void sst_eddy_visc_blending(const GasDev& g, const double* s, 
   const double strain = sqrt(2.0 * ss);
   mut = s[0] * SST_A1 * s[5] / fmax(SST_A1 * s[6], g.scaling * strain * f2);
 }
+// turbKWWilcox::EddyViscAndBlending turbulence.cpp:412-430 with OmegaTilda :339-351
+__device__ inline void kw_eddy_visc_blending(const GasDev& g, const double* s, const double* vg,
+                                             double& mut, double& f1, double& f2) {
+  const double trace = vg[0] + vg[4] + vg[8];
+  double ss = 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double a = 0.5 * (vg[3 * r + c] + vg[3 * c + r]) - (r == c ? 1.0 / 3.0 * trace : 0.0);
+      ss += a * a;
+    }
+  const double lim = g.scaling * 0.875 * sqrt(2.0 * ss / 0.09);
+  f1 = 1.0;
+  f2 = 0.0;
+  mut = s[0] * s[5] / fmax(s[6], lim);
+}
+// turbKWWilcox::Beta / FBeta / Xw / StrainKI turbulence.cpp:291-337
+__device__ inline double kw_beta(const GasDev& g, const double* s, const double* vg) {
+  double W[9], K[9];
+  const double trace = vg[0] + vg[4] + vg[8];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      W[3 * r + c] = 0.5 * (vg[3 * r + c] - vg[3 * c + r]);
+      K[3 * r + c] = 0.5 * (vg[3 * r + c] + vg[3 * c + r] - (r == c ? trace : 0.0));
+    }
+  double ddot = 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double ww = 0.0;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) ww += W[3 * r + m] * W[3 * m + c];
+      ddot += ww * K[3 * c + r];
+    }
+  const double bw = 0.09 * s[6];
+  const double xw = fabs(ddot / (bw * bw * bw)) * (g.scaling * g.scaling * g.scaling);
+  return 0.0708 * ((1.0 + 85.0 * xw) / (1.0 + 100.0 * xw));
+}
 // Green-Gauss gradients of k and omega at the lower d-face of cell qU
 // (ScalarGradGG utility.cpp:138-188 on the face-centred dual volume)
 __device__ inline void turb_face_grads(const BlockDev& b, int d, long qU, double* kg,
@@ -1477,7 +1519,8 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
       double wdist = cD * b.wdist[qU] + cU * b.wdist[qL];
       if (wdist < 0.0 && wdist > -1.0e-10) wdist = 0.0;
       double mut, f1, f2;
-      sst_eddy_visc_blending(g, sf, G, kg, wg, muf, wdist, mut, f1, f2);
+      if (g.wilcox) kw_eddy_visc_blending(g, sf, G, mut, f1, f2);
+      else sst_eddy_visc_blending(g, sf, G, kg, wg, muf, wdist, mut, f1, f2);
       // viscousFlux::CalcFlux
       const double mu = g.scaling * muf, mt = g.scaling * mut;
       const double lambda = -(2.0 / 3.0) * (mu + mt);
@@ -1489,14 +1532,16 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
         tau[r] = lambda * trace * n[r] + (mu + mt) * mm;
       }
       const double kk = conductivity(g, temperature(g, sf)) * g.scaling;
-      const double kt = mt * g.cp / 0.9;
+      const double kt = mt * g.cp / g.turb_prandtl;
       const double tg = grad[0][3] * n[0] + grad[1][3] * n[1] + grad[2][3] * n[2];
+      // UseUnlimitedEddyVisc (Wilcox): the k / omega diffusion takes rho k / omega
+      const double mtt = g.scaling * turb_diff_visc(g, sf, mut);
       double f[AGX_NEQ];
       f[0] = 0.0;
       f[1] = tau[0]; f[2] = tau[1]; f[3] = tau[2];
       f[4] = dot3(tau, sf + 1) + (kk + kt) * tg;
-      f[5] = (mu + sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1) * mt) * dot3(kg, n);
-      f[6] = (mu + sst_blend(SST_SIGMA_W1, SST_SIGMA_W2, f1) * mt) * dot3(wg, n);
+      f[5] = (mu + turb_sigma_k(g, f1) * mtt) * dot3(kg, n);
+      f[6] = (mu + turb_sigma_w(g, f1) * mtt) * dot3(wg, n);
       // this cell is the right cell of its lower face (+), the left of its upper (-)
       for (int e = 0; e < AGX_NEQ; ++e) res[e] += (up ? -1.0 : 1.0) * f[e] * n[3];
       for (int e = 0; e < 9; ++e) vgc[e] += (1.0 / 6.0) * G[e];
@@ -1522,22 +1567,18 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
     // ViscousCellSpectralRadius turbulence.cpp:797-815 with the LOWER face's mut, f1
     const double fmag = 0.5 * (b.fa[d][3][q] + b.fa[d][3][q + s]);
     const double vsr = visc_max_term(g, sc[0]) *
-                       (g.scaling * (muc * g.inv_prandtl + mut_lo / 0.9)) * fmag * fmag / vol;
+                       (g.scaling * (muc * g.inv_prandtl + mut_lo / g.turb_prandtl)) * fmag * fmag / vol;
     sr += vsr * sp.visc_cfl_coeff;
     diag += 2.0 * vsr;
     const double tvsr = g.scaling * (fmag * fmag / vol) / sc[0] *
-                        (muc + sst_blend(SST_SIGMA_K1, SST_SIGMA_K2, f1_lo) * mut_lo);
+                        (muc + turb_sigma_k(g, f1_lo) * turb_diff_visc(g, sc, mut_lo));
     srt += tvsr * sp.visc_cfl_coeff;
     diag_t += 2.0 * tvsr;
   }
   // ---- source terms of the cell, turbKWSst::CalcTurbSrc turbulence.cpp:637-690 ----
   {
     const double inv_sc = 1.0 / g.scaling;
-    const double cdkw = sst_cdkw(sc, kgc, wgc);
-    const double gam = sst_blend(SST_GAMMA1, SST_GAMMA2, f1c);
-    const double beta = sst_blend(SST_BETA1, SST_BETA2, f1c);
     const double tke_dest = inv_sc * SST_BETA_STAR * (sc[0] * sc[5] * sc[6] * 1.0);
-    const double omg_dest = inv_sc * beta * (sc[0] * sc[6] * sc[6]);
     const double lambda = -(2.0 / 3.0) * mutc;
     const double trace = vgc[0] + vgc[4] + vgc[8];
     double ddot = 0.0;
@@ -1548,11 +1589,27 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
                            2.0 / 3.0 * sc[0] * sc[5] * id;
         ddot += tau * vgc[3 * c + r];
       }
-    double tke_prod = fmax(fmin(g.scaling * ddot, SST_KPROD2DEST * tke_dest), 0.0);
-    const double omg_prod = fmax(gam * sc[0] / mutc * tke_prod, 0.0);
-    const double omg_cd = g.scaling * (1.0 - f1c) * cdkw;
-    res[5] -= (tke_prod - tke_dest) * vol;
-    res[6] -= (omg_prod - omg_dest + omg_cd) * vol;
+    double beta;
+    if (g.wilcox) {      // turbKWWilcox::CalcTurbSrc turbulence.cpp:359-407
+      beta = kw_beta(g, sc, vgc);
+      const double omg_dest = inv_sc * beta * (sc[0] * sc[6] * sc[6]);
+      const double tke_prod = fmax(g.scaling * ddot, 0.0);
+      const double omg_prod = fmax(0.52 * sc[6] / sc[5] * tke_prod, 0.0);
+      const double kw = dot3(kgc, wgc);
+      const double omg_cd = g.scaling * (kw <= 0.0 ? 0.0 : 0.125) * (sc[0] / sc[6] * kw);
+      res[5] -= (tke_prod - tke_dest) * vol;
+      res[6] -= (omg_prod - omg_dest + omg_cd) * vol;
+    } else {
+      const double cdkw = sst_cdkw(sc, kgc, wgc);
+      const double gam = sst_blend(SST_GAMMA1, SST_GAMMA2, f1c);
+      beta = sst_blend(SST_BETA1, SST_BETA2, f1c);
+      const double omg_dest = inv_sc * beta * (sc[0] * sc[6] * sc[6]);
+      const double tke_prod = fmax(fmin(g.scaling * ddot, SST_KPROD2DEST * tke_dest), 0.0);
+      const double omg_prod = fmax(gam * sc[0] / mutc * tke_prod, 0.0);
+      const double omg_cd = g.scaling * (1.0 - f1c) * cdkw;
+      res[5] -= (tke_prod - tke_dest) * vol;
+      res[6] -= (omg_prod - omg_dest + omg_cd) * vol;
+    }
     const double src_sr = -2.0 * SST_BETA_STAR * sc[6] * vol * inv_sc;   // SrcSpecRad :739-747
     srt -= src_sr;
     diag_t -= src_sr;

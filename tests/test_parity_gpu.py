@@ -612,6 +612,27 @@ def test_rae2822_gpu_reproduces_reference_truth(agx_rans):
     sol.close()
 
 
+@pytest.mark.gpu
+def test_turbflatplate_wilcox_parity_and_truth(agx_rans, oracle):
+    """The reference's turbFlatPlate case (k-omega Wilcox 2006, stagnation inlet,
+    pressure outlet, viscous + slip wall on one surface): HIP vs oracle per iteration,
+    and the HIP library alone reproduces the reference's truth digits after 20
+    iterations (regressionTests.py:378-380)."""
+    import json
+    from conftest import GOLDEN
+    case = golden_case("turbFlatPlate")
+    _close(*run_pair(agx_rans, oracle, case, 3, fields=("state", "residual", "dt")))
+    with open(os.path.join(GOLDEN, "regression_truths.json")) as fh:
+        spec = json.load(fh)["turbFlatPlate"]
+    sol = Solver(agx_rans, golden_case("turbFlatPlate"))
+    out = sol.run(spec["iterations"])
+    for idx, (got, t) in enumerate(zip(out["norm"], spec["truth"])):
+        if idx in spec["ignore"]:
+            continue
+        assert f"{got:.4e}" == f"{t:.4e}", (idx, got, t)
+    sol.close()
+
+
 RANS_WALL = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristic", 1),
              4: ("characteristic", 1), 5: ("characteristic", 1), 6: ("characteristic", 1)}
 
@@ -626,6 +647,10 @@ RANS_WALL = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristi
     # eddy viscosity + diagonal turbulence block); and its point-Jacobi twin
     dict(matrix_solver="blusgs", matrix_sweeps=2),
     dict(matrix_solver="bdplur", matrix_sweeps=3, inviscid_flux="ausm"),
+    # k-omega Wilcox 2006 (stress-limited eddy viscosity, unlimited one in the k / omega
+    # diffusion, vortex-stretching beta, cross diffusion switch), scalar and block
+    dict(turbulence_model="kOmegaWilcox2006", matrix_solver="lusgs", matrix_sweeps=2),
+    dict(turbulence_model="kOmegaWilcox2006", matrix_solver="blusgs", inviscid_flux="ausm"),
 ])
 def test_rans_synthetic_parity(agx_rans, oracle, kw):
     """3-D boxes with a viscous wall: both flux functions, MUSCL and WENO, LU-SGS and
