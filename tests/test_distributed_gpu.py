@@ -24,12 +24,20 @@ KW = {
     "dplur": dict(inviscid_flux="ausm", limiter="none", time_integration="implicitEuler",
                   matrix_solver="dplur", matrix_sweeps=4, cfl=5.0),
     "lusgs": dict(time_integration="implicitEuler", matrix_solver="lusgs", cfl=5.0),
+    # rans (7-equation build): eddy viscosity / blending functions -- and with BLU-SGS the
+    # velocity gradients -- of the cells across the ranks
+    "rans": dict(bcs={3: ("viscousWall", 2), 1: ("characteristic", 1),
+                      2: ("characteristic", 1), 4: ("characteristic", 1)},
+                 equation_set="rans", turbulence_model="sst2003",
+                 time_integration="implicitEuler", matrix_solver="blusgs", matrix_sweeps=2,
+                 cfl=10.0),
 }
 DIMS = (70, 9, 8)
 
 
 def _case(kind, ranks):
-    return synthetic.stacked_blocks_case(DIMS, nblocks=2, axis="k", stretch=1.1,
+    dims = (20, 9, 8) if kind == "rans" else DIMS
+    return synthetic.stacked_blocks_case(dims, nblocks=2, axis="k", stretch=1.1,
                                          ranks=ranks, **KW[kind])
 
 
@@ -57,7 +65,7 @@ def _worker(rank, port, kind, q, in_library=False):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=2)
     import aither_amd
-    agx = aither_amd.load()
+    agx = aither_amd.load(7 if kind == "rans" else 5)
     case = _case(kind, [0, 1])
     if in_library:   # agx_iterate drives the remote connection (host-staged slabs over gloo)
         sol = Solver(agx, case, rank=rank, exchange=DistExchange(2))
@@ -97,7 +105,7 @@ def test_rccl_transport_single_rank(agx, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,in_library", [(k, False) for k in sorted(KW)] +
-                         [("rk4", True), ("lusgs", True)])
+                         [("rk4", True), ("lusgs", True), ("rans", True)])
 def test_two_ranks_on_one_gpu(oracle, kind, in_library):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
