@@ -62,7 +62,9 @@ class BcState(C.Structure):
                 ("length_scale", C.c_double),
                 ("is_isothermal", C.c_int32), ("is_heat_flux", C.c_int32),
                 ("is_nonreflecting", C.c_int32), ("pad_", C.c_int32),
-                ("turb_intensity", C.c_double), ("eddy_visc_ratio", C.c_double)]
+                ("turb_intensity", C.c_double), ("eddy_visc_ratio", C.c_double),
+                ("von_karman", C.c_double), ("wall_constant", C.c_double),
+                ("is_wall_law", C.c_int32), ("pad2_", C.c_int32)]
 
 
 class BcSurface(C.Structure):

@@ -79,8 +79,15 @@ def nondim_state(deck, gas, st):
         if st.get("heatFlux") is not None:
             out.is_heat_flux = 1
             out.wall_heat_flux = st.get("heatFlux") / ((a_ref / l_ref) ** 3.0)
-        if st.get("wallTreatment", "lowRe") != "lowRe":
-            raise NotImplementedError("wall-law boundaries are out of scope")
+        treatment = st.get("wallTreatment", "lowRe")
+        if treatment not in ("lowRe", "wallLaw"):
+            raise NotImplementedError(f"wallTreatment {treatment}")
+        if treatment == "wallLaw":
+            if not deck.is_rans() or out.is_isothermal or out.is_heat_flux:
+                raise NotImplementedError("wall functions: adiabatic walls of rans runs")
+            out.is_wall_law = 1
+            out.von_karman = st.get("vonKarmen", 0.41)        # inputStates.hpp:343-344
+            out.wall_constant = st.get("wallConstant", 5.5)
     elif kind == "periodic":
         pass
     else:

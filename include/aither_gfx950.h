@@ -172,6 +172,10 @@ typedef struct agx_bc_state {
   /* farfield turbulence of the state (ApplyFarfieldTurbBC, primitive.cpp:83-98):
    * turbulenceIntensity and eddyViscosityRatio; read by rans runs only */
   double turb_intensity, eddy_visc_ratio;
+  /* viscousWall(wallTreatment=wallLaw): von Karman constant and wall constant
+   * (inputStates.hpp:343-345); rans library, adiabatic walls */
+  double von_karman, wall_constant;
+  int32_t is_wall_law, pad2_;
 } agx_bc_state;
 
 /* one boundarySurface (boundaryConditions.hpp:55-150): index ranges are the

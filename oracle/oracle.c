@@ -41,6 +41,11 @@ static int fail(const char *fmt, ...) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* wallVars wallData.hpp:33-62 (what the solver reads of it) */
+typedef struct wall_vars_s {
+  double yplus, heat_flux, density, temperature, viscosity, turb_eddy_visc, friction_velocity,
+         shear[3], tke, sdr;
+} wall_vars;
 typedef struct {
   int ni, nj, nk, ng, parent, gpos;
   int ci, cj, ck;        /* ghost-padded cell dims */
@@ -65,6 +70,10 @@ typedef struct {
    * (eddyViscosity_, f1_, f2_) interleaved [cells_g][3]; tkeGrad_, omegaGrad_ [cells][3] */
   double *specrad_t, *a_t, *ainv_t, *turb3, *kgrad, *wgrad;
   double *am_t, *aminv_t; /* block-matrix solvers: diagonal of the turbulence block [cells][2] */
+  /* wallData_ of the wall-law surfaces: per surface the offset of its faces in wallv
+   * (-1: not a wall-law surface), wallVars of every face */
+  long *wall_off;
+  struct wall_vars_s *wallv;
   int nsurf;
   agx_bc_surface *surf;
   int nsurf_i, nsurf_j, nsurf_k;
@@ -606,6 +615,105 @@ static void extrap_hold(const double *bnd, double factor, const double *in,
 
 /* GetGhostState ghostStates.cpp:62-689 (laminar, low-Re walls, reflecting
  * inlet/outlet) */
+static int is_wilcox_fwd(const ora_ctx *c) { return c->cfg.turbulence_model == AGX_TURB_KW_WILCOX2006; }
+/* ---- wall functions: wallLaw::AdiabaticBCs wallLaw.cpp:30-77 with its helpers
+ * (:182-289) and FindRoot (Ridder, utility.hpp:130-184).  The function whose root is
+ * sought has side effects: what is kept afterwards belongs to its LAST evaluation. */
+typedef struct {
+  const ora_ctx *c;
+  const double *state;
+  double vonKarmen, wallDist, yplus0, beta, gamma, q, phi, yplusWhite, uStar, uplus, tW, rhoW,
+         muW, mutW, kW, recoveryFactor, velTanMag, heatFlux, yplus_last;
+} wall_law;
+static double sign_of(double v) { return (double)((0.0 < v) - (v < 0.0)); }
+static double wl_func(wall_law *w, double yplus) {
+  const ora_ctx *c = w->c;
+  /* CalcVelocities, UpdateGamma, UpdateConstants, CalcYplusWhite, CalcYplusRoot */
+  w->uplus = (w->wallDist * w->rhoW * w->velTanMag) / (w->muW * yplus);
+  w->uStar = w->velTanMag / w->uplus;
+  w->gamma = w->recoveryFactor * w->uStar * w->uStar / (2.0 * c->cp * w->tW);
+  w->beta = w->heatFlux * w->muW / (w->rhoW * w->tW * w->kW * w->uStar);
+  w->q = sqrt(w->beta * w->beta + 4.0 * w->gamma);
+  w->phi = asin(-w->beta / w->q);
+  w->yplusWhite = exp((w->vonKarmen / sqrt(w->gamma)) *
+                      (asin((2.0 * w->gamma * w->uplus - w->beta) / w->q) - w->phi)) * w->yplus0;
+  w->yplus_last = yplus;
+  const double ku = w->vonKarmen * w->uplus;
+  return yplus - (w->uplus + w->yplusWhite -
+                  w->yplus0 * (1.0 + ku + 0.5 * ku * ku + (1.0 / 6.0) * pow(ku, 3.0)));
+}
+static void wl_find_root(wall_law *w, double x1, double x2, double tol) {
+  double f1 = wl_func(w, x1), f2 = wl_func(w, x2);
+  if (sign_of(f1) == sign_of(f2) && sign_of(f1) != 0.0) return;   /* (reference: message, midpoint) */
+  for (int ii = 0; ii < 100; ++ii) {
+    const double x3 = 0.5 * (x1 + x2);
+    const double f3 = wl_func(w, x3);
+    if (f3 == 0.0) return;
+    const double denom = sqrt(fabs(f3 * f3 - f1 * f2));
+    if (denom == 0.0) return;
+    const double fac = sign_of(f1 - f2);
+    const double x4 = x3 + (x3 - x1) * (fac * f3) / denom;
+    const double f4 = wl_func(w, x4);
+    if (f4 == 0.0) return;
+    if (sign_of(f4) != sign_of(f3)) { x1 = x3; f1 = f3; x2 = x4; f2 = f4; }
+    else if (sign_of(f4) != sign_of(f1)) { x2 = x4; f2 = f4; }
+    else { x1 = x4; f1 = f4; }
+    if (fabs(x2 - x1) <= tol) return;
+  }
+}
+static void wall_law_adiabatic(const ora_ctx *c, const double *state, double wallDist,
+                               const double *normArea, const double *velWall, int isLower,
+                               double vonKarmen, double wallConst, wall_vars *wv) {
+  wall_law w;
+  memset(&w, 0, sizeof w);
+  w.c = c; w.state = state; w.vonKarmen = vonKarmen; w.wallDist = wallDist;
+  w.yplus0 = exp(-vonKarmen * wallConst);
+  w.heatFlux = 0.0;
+  const double vel[3] = {state[1] - velWall[0], state[2] - velWall[1], state[3] - velWall[2]};
+  const double vn = dot3(vel, normArea);
+  const double velTan[3] = {vel[0] - vn * normArea[0], vel[1] - vn * normArea[1],
+                            vel[2] - vn * normArea[2]};
+  w.velTanMag = mag3(velTan);
+  const double t = temperature(c, state);
+  w.recoveryFactor = pow(c->prandtl, 1.0 / 3.0);
+  const double tW = t + 0.5 * w.recoveryFactor * w.velTanMag * w.velTanMag / c->cp;
+  /* SetWallVars */
+  w.tW = tW;
+  w.rhoW = state[4] / ((0.0 + 1.0 * c->cfg.gas.gas_constant) * tW);
+  w.muW = viscosity(c, tW) * c->scaling;
+  w.kW = conductivity(c, tW) * c->scaling;
+  wl_find_root(&w, 1.0e1, 1.0e4, 1.0e-8);
+  wv->yplus = w.yplus_last;
+  wv->heat_flux = 0.0;
+  /* CalcTurbVars with EddyVisc, wallLaw.cpp:243-279 */
+  {
+    const double dYplusWhite =
+        2.0 * w.yplusWhite * w.vonKarmen * sqrt(w.gamma) / w.q *
+        sqrt(fmax(1.0 - pow(2.0 * w.gamma * w.uplus - w.beta, 2.0) / (w.q * w.q), 0.0));
+    const double ku = w.vonKarmen * w.uplus;
+    w.mutW = w.muW * (1.0 + dYplusWhite - w.vonKarmen * w.yplus0 * (1.0 + ku + 0.5 * ku * ku)) -
+             viscosity(c, t) * c->scaling;
+    w.mutW = fmax(w.mutW, 0.0);
+    const double wallBeta = is_wilcox_fwd(c) ? 0.0708 : 0.075;
+    double wi = 6.0 * w.muW / (wallBeta * w.rhoW * wallDist * wallDist);
+    wi *= c->scaling;
+    double wo = w.uStar / (sqrt(0.09) * w.vonKarmen * wallDist);
+    wo *= c->scaling;
+    wv->sdr = sqrt(wi * wi + wo * wo);
+    wv->tke = wv->sdr * w.mutW / state[0] * (1.0 / c->scaling);
+  }
+  wv->density = w.rhoW;
+  wv->temperature = w.tW;
+  wv->viscosity = w.muW;
+  wv->turb_eddy_visc = w.mutW;
+  wv->friction_velocity = w.uStar;
+  const double ssm = w.uStar * w.uStar * w.rhoW;
+  for (int q = 0; q < 3; ++q) {
+    wv->shear[q] = ssm * velTan[q] / w.velTanMag;
+    if (!isLower) wv->shear[q] *= -1.0;
+  }
+}
+
 /* what the nonreflecting (LODI) branches of GetGhostState read besides the interior
  * state: dt and the state at time n of the adjacent cell, its pressure and velocity
  * gradients, Mach mean / maximum over the surface (procBlock.cpp:6233-6262) */
@@ -622,19 +730,19 @@ static void apply_farfield_turb(const ora_ctx *c, double *s, const double *vel,
 static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
                           const double *areaUnit, int surf, const agx_bc_state *d,
                           int layer, double wallDist, double nuW, const nr_data *nr,
-                          double *ghost);
+                          wall_vars *wv, double *ghost);
 /* nuW: kinematic viscosity of the wall-adjacent cell (rans viscous walls,
  * procBlock.cpp:2814-2820) */
 static int ghost_state(const ora_ctx *c, const double *interior, int bc,
                        const double *areaVec, int surf,
                        const agx_bc_state *d, int layer, double wallDist, double nuW,
                        double *ghost) {
-  return ghost_state_nr(c, interior, bc, areaVec, surf, d, layer, wallDist, nuW, NULL, ghost);
+  return ghost_state_nr(c, interior, bc, areaVec, surf, d, layer, wallDist, nuW, NULL, NULL, ghost);
 }
 static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
                           const double *areaVec, int surf,
                           const agx_bc_state *d, int layer, double wallDist, double nuW,
-                          const nr_data *nr, double *ghost) {
+                          const nr_data *nr, wall_vars *wv, double *ghost) {
   const int rans = NEQ > NF;
   if (rans && bc != AGX_BC_SLIPWALL && bc != AGX_BC_VISCOUSWALL && bc != AGX_BC_CHARACTERISTIC &&
       bc != AGX_BC_STAGNATION_INLET && bc != AGX_BC_PRESSURE_OUTLET)
@@ -666,7 +774,25 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
       const double rho = ghost[4] / (R * tGhost);
       ghost[0] = rho * (interior[0] / interior[0]);
     }
-    if (rans) {
+    /* wall functions (adiabatic, ghostStates.cpp:245-259): the wall law gives k and
+     * omega at the wall unless y+ < 10 switches the face back to the low-Re treatment */
+    int lowRe = 1;
+    if (d->is_wall_law) {
+      wall_vars loc;
+      wall_vars *w = wv ? wv : &loc;
+      wall_law_adiabatic(c, interior, wallDist, n, d->velocity, isLower, d->von_karman,
+                         d->wall_constant, w);
+      lowRe = w->yplus < 10.0;                       /* wallVars::SwitchToLowRe */
+      if (rans && !lowRe) {
+        ghost[5] = 2.0 * w->tke - interior[5];
+        ghost[6] = 2.0 * w->sdr - interior[6];
+        if (layer > 1) {
+          ghost[5] = layer * ghost[5] - w->tke;
+          ghost[6] = layer * ghost[6] - w->sdr;
+        }
+      }
+    }
+    if (rans && lowRe) {
       /* low-Re wall, ghostStates.cpp:261-279: k = 0 at the face, omega of Menter's
        * wall value (WallBeta = beta1, turbulence.hpp:577) */
       ghost[5] = -1.0 * interior[5];
@@ -967,9 +1093,14 @@ static int assign_ghost_faces(ora_ctx *c, blk_t *b, int viscous) {
            * last UpdateAuxillaryVariables (procBlock.cpp:2814-2820) */
           const long qa = CI(b, wi, wj, wk);
           const double nuW = (NEQ > NF && viscous) ? b->visc[qa] / b->state[NEQ * qa] : 0.0;
+          /* wallData_ is written by the first viscous ghost layer (procBlock.cpp:6289-6292) */
+          wall_vars *wv = NULL;
+          if (viscous && layer == 1 && bc == AGX_BC_VISCOUSWALL && q->state.is_wall_law &&
+              b->wall_off && b->wall_off[sn] >= 0)
+            wv = b->wallv + b->wall_off[sn] + (long)(a2 - r2s) * (r1e - r1s) + (a1 - r1s);
           if (ghost_state_nr(c, b->state + NEQ * CI(b, i, j, k), bc, area, st,
                              &q->state, layer, b->wdist ? b->wdist[qa] : 0.0, nuW,
-                             is_nr ? &nr : NULL, g))
+                             is_nr ? &nr : NULL, wv, g))
             return 1;
           memcpy(b->state + NEQ * CI(b, gi, gj, gk), g, sizeof(double) * NEQ);
         }
@@ -1759,6 +1890,45 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
         }
         const double *area = b->fa[d] + 4 * FI(b, d, i, j, k);
         double f[NEQM], mut = 0.0, f1 = 0.0, f2 = 0.0;
+        /* wall-law boundary face (procBlock.cpp:1259-1299): the stored wall data give the
+         * state, viscosities and the flux itself, unless y+ < 10 switched the face to
+         * the low-Re treatment */
+        const wall_vars *wl = NULL;
+        const agx_bc_surface *wsurf = NULL;
+        if (rans && b->wall_off && ((d == 0 ? i : d == 1 ? j : k) == 0 ||
+                                    (d == 0 ? i : d == 1 ? j : k) == nn[d])) {
+          const int stype = 2 * d + ((d == 0 ? i : d == 1 ? j : k) == 0 ? 1 : 2);
+          wsurf = get_bc_surface(b, i, j, k, stype);
+          if (wsurf && wsurf->bc_type == AGX_BC_VISCOUSWALL && wsurf->state.is_wall_law) {
+            const long sn = wsurf - b->surf;
+            int r1s, r1e, r2s, r2e, r3s;
+            surf_ranges(wsurf, d, &r1s, &r1e, &r2s, &r2e, &r3s);
+            const int c3[3] = {i, j, k};
+            const int a1 = c3[(d + 1) % 3], a2 = c3[(d + 2) % 3];
+            const wall_vars *w = b->wallv + b->wall_off[sn] + (long)(a2 - r2s) * (r1e - r1s) +
+                                 (a1 - r1s);
+            if (!(w->yplus < 10.0)) wl = w;
+          }
+        }
+        if (wl) {
+          const double invSc = 1.0 / c->scaling;
+          f1 = 1.0; f2 = 1.0;
+          mu = wl->viscosity * invSc;
+          mut = wl->turb_eddy_visc * invSc;
+          /* wallData::WallState wallData.cpp:299-313 */
+          st[0] = wl->density;
+          for (int q3 = 0; q3 < 3; ++q3) st[1 + q3] = wsurf->state.velocity[q3];
+          st[4] = wl->density * (0.0 + 1.0 * c->cfg.gas.gas_constant) * wl->temperature;
+          st[5] = wl->tke; st[6] = wl->sdr;
+          /* viscousFlux::CalcWallLawFlux viscousFlux.cpp:214-247 (WallSigmaK / W: sigma_k1 /
+           * sigma_w1 of SST, 0 of the base class -- Wilcox has no override) */
+          const double wsk = is_wilcox(c) ? 0.0 : SST_SIGMA_K1, wsw = is_wilcox(c) ? 0.0 : SST_SIGMA_W1;
+          f[0] = 0.0;
+          for (int q3 = 0; q3 < 3; ++q3) f[1 + q3] = wl->shear[q3];
+          f[4] = dot3(wl->shear, wsurf->state.velocity) + wl->heat_flux;
+          f[5] = (wl->viscosity + wsk * wl->turb_eddy_visc) * dot3(kGrad, area);
+          f[6] = (wl->viscosity + wsw * wl->turb_eddy_visc) * dot3(wGrad, area);
+        } else
         if (rans) {
           /* state.LimitTurb, wall distance at the face, eddy viscosity and blending
            * (procBlock.cpp:1303-1355; the wall distance always by the two-cell rule) */
@@ -1771,7 +1941,7 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
           if (is_wilcox(c)) kw_eddy_visc_blending(c, st, velGrad, &mut, &f1, &f2);
           else sst_eddy_visc_blending(c, st, velGrad, kGrad, wGrad, mu, wDist, &mut, &f1, &f2);
         }
-        visc_flux(c, velGrad, tGrad, area, st, mu, mut, f1, kGrad, wGrad, f);
+        if (!wl) visc_flux(c, velGrad, tGrad, area, st, mu, mut, f1, kGrad, wGrad, f);
         const int idx[3] = {i, j, k};
         if (idx[d] > 0) {
           const long p = PI(b, i - o[0], j - o[1], k - o[2]);
@@ -2320,6 +2490,8 @@ static void free_blk(blk_t *b) {
   }
   free(b->surf);
   b->surf = NULL;
+  free(b->wall_off); b->wall_off = NULL;
+  free(b->wallv); b->wallv = NULL;
 }
 void ora_ctx_destroy(ora_ctx *c) {
   if (c && c->have_cfg) --g_live_cfg;
@@ -2446,6 +2618,20 @@ int ora_block_set_bcs(ora_ctx *c, int id, int n, const agx_bc_surface *s) {
     const int st = surf_type(&s[q]);
     if (st <= 2) b->nsurf_i++; else if (st <= 4) b->nsurf_j++; else b->nsurf_k++;
   }
+  /* wallData_ (procBlock.hpp:99): one wallVars per face of every wall-law surface */
+  free(b->wall_off); free(b->wallv);
+  b->wall_off = (long *)malloc(sizeof(long) * (n > 0 ? n : 1));
+  long total = 0;
+  for (int q = 0; q < n; ++q) {
+    b->wall_off[q] = -1;
+    if (s[q].bc_type != AGX_BC_VISCOUSWALL || !s[q].state.is_wall_law) continue;
+    const int d3 = (surf_type(&s[q]) - 1) / 2;
+    int r1s, r1e, r2s, r2e, r3s;
+    surf_ranges(&s[q], d3, &r1s, &r1e, &r2s, &r2e, &r3s);
+    b->wall_off[q] = total;
+    total += (long)(r1e - r1s) * (r2e - r2s);
+  }
+  b->wallv = (wall_vars *)calloc(total > 0 ? total : 1, sizeof(wall_vars));
   return 0;
 }
 int ora_conn_create(ora_ctx *c, const agx_connection *cc, int *id) {
