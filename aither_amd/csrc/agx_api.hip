@@ -60,6 +60,9 @@ struct Block {
   int* nr_off_dev = nullptr;
   double* nr_mem = nullptr;
   long nr_max = 0;            // cells of the largest such surface (0: none)
+  // wall-law surfaces (rans): offsets | wallData_ of their faces (BlockDev)
+  int* wall_off_dev = nullptr;
+  double* wall_mem = nullptr;
 };
 
 struct ConnSide {          // what side s receives / sends
@@ -866,6 +869,8 @@ void agx_ctx_destroy(agx_ctx* c) {
     if (b.surf_dev) hipFree(b.surf_dev);
     if (b.nr_off_dev) hipFree(b.nr_off_dev);
     if (b.nr_mem) hipFree(b.nr_mem);
+    if (b.wall_off_dev) hipFree(b.wall_off_dev);
+    if (b.wall_mem) hipFree(b.wall_mem);
   }
   for (auto& k : c->conns) {
     for (int s = 0; s < 2; ++s) {
@@ -1099,6 +1104,12 @@ int agx_block_set_bcs(agx_ctx* c, int id, int n, const agx_bc_surface* s) {
     const int t = s[q].bc_type;
     if (t < AGX_BC_SLIPWALL || t > AGX_BC_PERIODIC) return fail("unknown bc type %d", t);
     if (t == AGX_BC_INTERBLOCK || t == AGX_BC_PERIODIC) n_conn[st - 1]++; else n_other[st - 1]++;
+    if (t == AGX_BC_VISCOUSWALL && s[q].state.is_wall_law) {
+      // wall functions: the 7-equation library, adiabatic walls (wallLaw::AdiabaticBCs)
+      if (AGX_NEQ == 5) return fail("wallTreatment=wallLaw needs the rans library");
+      if (s[q].state.is_isothermal || s[q].state.is_heat_flux)
+        return fail("wallTreatment=wallLaw: adiabatic walls only");
+    }
   }
   for (int q = 0; q < 6; ++q)
     b.d.side_conn[q] = n_conn[q] == 0 ? 0 : (n_other[q] == 0 ? 1 : 2);
@@ -1130,6 +1141,31 @@ int agx_block_set_bcs(agx_ctx* c, int id, int n, const agx_bc_surface* s) {
     b.d.nr_off = b.nr_off_dev;
     b.d.nr_grad = b.nr_mem;
     b.d.nr_mach = b.nr_mem + 12 * total;
+  }
+  // wall-law surfaces keep the wall data of their faces (wallData_, wallData.hpp:33-62)
+  // from the viscous ghost fill to the viscous fluxes of the same residual
+  if (b.wall_off_dev) HIPCHK(hipFree(b.wall_off_dev));
+  if (b.wall_mem) HIPCHK(hipFree(b.wall_mem));
+  b.wall_off_dev = nullptr; b.wall_mem = nullptr;
+  b.d.wall_off = nullptr; b.d.wallv = nullptr;
+  std::fill(off.begin(), off.end(), -1);
+  total = 0;
+  for (int q = 0; q < n; ++q) {
+    if (s[q].bc_type != AGX_BC_VISCOUSWALL || !s[q].state.is_wall_law) continue;
+    const int st = surface_type(s[q]);
+    const int d3 = (st - 1) / 2, d1 = (d3 + 1) % 3, d2 = (d3 + 2) % 3;
+    const int lo[3] = {s[q].imin, s[q].jmin, s[q].kmin}, hi[3] = {s[q].imax, s[q].jmax, s[q].kmax};
+    off[q] = (int)total;
+    total += (long)(hi[d1] - lo[d1]) * (hi[d2] - lo[d2]);
+  }
+  if (total > 0) {
+    HIPCHK(hipMalloc((void**)&b.wall_off_dev, sizeof(int) * n));
+    HIPCHK(hipMemcpy(b.wall_off_dev, off.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    const size_t nd = sizeof(WallVars) * (size_t)total;
+    HIPCHK(hipMalloc((void**)&b.wall_mem, nd));
+    HIPCHK(hipMemset(b.wall_mem, 0, nd));        // y+ = 0: low-Re until the first ghost fill
+    b.d.wall_off = b.wall_off_dev;
+    b.d.wallv = (WallVars*)b.wall_mem;
   }
   return 0;
 }

@@ -756,13 +756,100 @@ __device__ inline void apply_farfield_turb(const GasDev& g, double* s, const dou
                           AGX_TURB_MIN);
   }
 }
+// ---- wall functions (rans): wallLaw::AdiabaticBCs wallLaw.cpp:30-77 with its helpers
+// (:182-289) and Ridder's FindRoot (utility.hpp:130-184).  The function whose root is
+// sought has side effects: what is kept belongs to its LAST evaluation.
+struct WallVars {     // wallVars wallData.hpp:33-62, what the solver reads (12 doubles)
+  double yplus, heat_flux, density, temperature, viscosity, turb_eddy_visc, friction_velocity,
+         shear[3], tke, sdr;
+};
+struct WallLawDev {
+  double von_karman, wall_dist, yplus0, beta, gamma, q, phi, yplus_white, u_star, uplus, tw, rho_w,
+         mu_w, k_w, recovery, vel_tan, heat_flux, yplus_last, cp;
+  __device__ double func(double yplus) {
+    uplus = (wall_dist * rho_w * vel_tan) / (mu_w * yplus);
+    u_star = vel_tan / uplus;
+    gamma = recovery * u_star * u_star / (2.0 * cp * tw);
+    beta = heat_flux * mu_w / (rho_w * tw * k_w * u_star);
+    q = sqrt(beta * beta + 4.0 * gamma);
+    phi = asin(-beta / q);
+    yplus_white = exp((von_karman / sqrt(gamma)) * (asin((2.0 * gamma * uplus - beta) / q) - phi)) *
+                  yplus0;
+    yplus_last = yplus;
+    const double ku = von_karman * uplus;
+    return yplus - (uplus + yplus_white -
+                    yplus0 * (1.0 + ku + 0.5 * ku * ku + (1.0 / 6.0) * (ku * ku * ku)));
+  }
+};
+__device__ __forceinline__ double sign_of(double v) { return (double)((0.0 < v) - (v < 0.0)); }
+__device__ inline void wall_law_adiabatic(const GasDev& g, const double* s, double wall_dist,
+                                          const double* n, const double* vel_wall, bool is_lower,
+                                          double von_karman, double wall_const, WallVars& wv) {
+  WallLawDev w;
+  w.von_karman = von_karman; w.wall_dist = wall_dist; w.yplus0 = exp(-von_karman * wall_const);
+  w.heat_flux = 0.0; w.cp = g.cp; w.yplus_last = 0.0;
+  w.beta = w.gamma = w.q = w.phi = w.yplus_white = w.u_star = w.uplus = 0.0;
+  const double vel[3] = {s[1] - vel_wall[0], s[2] - vel_wall[1], s[3] - vel_wall[2]};
+  const double vn = dot3(vel, n);
+  const double vt[3] = {vel[0] - vn * n[0], vel[1] - vn * n[1], vel[2] - vn * n[2]};
+  w.vel_tan = sqrt(dot3(vt, vt));
+  const double t = s[4] / (s[0] * g.R);
+  w.recovery = pow(g.prandtl, 1.0 / 3.0);
+  w.tw = t + 0.5 * w.recovery * w.vel_tan * w.vel_tan / g.cp;
+  w.rho_w = s[4] / (g.R * w.tw);
+  w.mu_w = viscosity(g, w.tw) * g.scaling;
+  w.k_w = conductivity(g, w.tw) * g.scaling;
+  {   // FindRoot(func, 1.0e1, 1.0e4, 1.0e-8)
+    double x1 = 1.0e1, x2 = 1.0e4;
+    double f1 = w.func(x1), f2 = w.func(x2);
+    if (!(sign_of(f1) == sign_of(f2) && sign_of(f1) != 0.0)) {
+      for (int it = 0; it < 100; ++it) {
+        const double x3 = 0.5 * (x1 + x2);
+        const double f3 = w.func(x3);
+        if (f3 == 0.0) break;
+        const double denom = sqrt(fabs(f3 * f3 - f1 * f2));
+        if (denom == 0.0) break;
+        const double x4 = x3 + (x3 - x1) * (sign_of(f1 - f2) * f3) / denom;
+        const double f4 = w.func(x4);
+        if (f4 == 0.0) break;
+        if (sign_of(f4) != sign_of(f3)) { x1 = x3; f1 = f3; x2 = x4; f2 = f4; }
+        else if (sign_of(f4) != sign_of(f1)) { x2 = x4; f2 = f4; }
+        else { x1 = x4; f1 = f4; }
+        if (fabs(x2 - x1) <= 1.0e-8) break;
+      }
+    }
+  }
+  wv.yplus = w.yplus_last;
+  wv.heat_flux = 0.0;
+  // CalcTurbVars with EddyVisc, wallLaw.cpp:243-279
+  const double dyw = 2.0 * w.yplus_white * w.von_karman * sqrt(w.gamma) / w.q *
+                     sqrt(fmax(1.0 - (2.0 * w.gamma * w.uplus - w.beta) *
+                                         (2.0 * w.gamma * w.uplus - w.beta) / (w.q * w.q), 0.0));
+  const double ku = w.von_karman * w.uplus;
+  const double mut_w = fmax(w.mu_w * (1.0 + dyw - w.von_karman * w.yplus0 * (1.0 + ku + 0.5 * ku * ku)) -
+                            viscosity(g, t) * g.scaling, 0.0);
+  const double wi = 6.0 * w.mu_w / ((g.wilcox ? 0.0708 : 0.075) * w.rho_w * wall_dist * wall_dist) *
+                    g.scaling;
+  const double wo = w.u_star / (sqrt(0.09) * w.von_karman * wall_dist) * g.scaling;
+  wv.sdr = sqrt(wi * wi + wo * wo);
+  wv.tke = wv.sdr * mut_w / s[0] * (1.0 / g.scaling);
+  wv.density = w.rho_w;
+  wv.temperature = w.tw;
+  wv.viscosity = w.mu_w;
+  wv.turb_eddy_visc = mut_w;
+  wv.friction_velocity = w.u_star;
+  const double ssm = w.u_star * w.u_star * w.rho_w;
+  for (int q = 0; q < 3; ++q) wv.shear[q] = (is_lower ? 1.0 : -1.0) * ssm * vt[q] / w.vel_tan;
+}
+
 // nu_w: kinematic viscosity of the wall-adjacent cell (rans viscous walls,
 // procBlock.cpp:2814-2820)
 __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
                                    const double* area_unit, int surf,
                                    const agx_bc_state& d, int layer,
                                    double wall_dist, double* gh,
-                                   const NrDev* nr = nullptr, double nu_w = 0.0) {
+                                   const NrDev* nr = nullptr, double nu_w = 0.0,
+                                   WallVars* wv = nullptr) {
   // rans: the other boundary types are not built (as in the oracle)
   if (AGX_NEQ > 5 && bc != AGX_BC_SLIPWALL && bc != AGX_BC_VISCOUSWALL &&
       bc != AGX_BC_CHARACTERISTIC && bc != AGX_BC_STAGNATION_INLET &&
@@ -790,7 +877,25 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
         const double tg = t - d.wall_heat_flux / conductivity(g, t) * 2.0 * wall_dist;
         gh[0] = gh[4] / (g.R * tg);
       }
-      if (AGX_NEQ > 5) {
+      // wall functions (adiabatic, ghostStates.cpp:245-259): k and omega at the wall from
+      // the wall law unless y+ < 10 switches the face back to the low-Re treatment
+      bool low_re = true;
+      if (AGX_NEQ > 5 && d.is_wall_law) {
+        WallVars loc;
+        WallVars& w = wv ? *wv : loc;
+        wall_law_adiabatic(g, in, wall_dist, n, d.velocity, surf % 2 == 1, d.von_karman,
+                           d.wall_constant, w);
+        low_re = w.yplus < 10.0;
+        if (!low_re) {
+          gh[AGX_NEQ - 2] = 2.0 * w.tke - in[AGX_NEQ - 2];
+          gh[AGX_NEQ - 1] = 2.0 * w.sdr - in[AGX_NEQ - 1];
+          if (layer > 1) {
+            gh[AGX_NEQ - 2] = layer * gh[AGX_NEQ - 2] - w.tke;
+            gh[AGX_NEQ - 1] = layer * gh[AGX_NEQ - 1] - w.sdr;
+          }
+        }
+      }
+      if (AGX_NEQ > 5 && low_re) {
         // low-Re wall, ghostStates.cpp:261-279: k = 0 at the face, Menter's wall omega
         // (WallBeta = beta1 = 0.075)
         gh[AGX_NEQ - 2] = -1.0 * in[AGX_NEQ - 2];

@@ -64,6 +64,9 @@ struct BlockDev {
   // surface's Mach {mean, max}
   const int* nr_off;
   double* nr_grad;
+  // wall-law surfaces (rans): offset of the surface's faces in wallv (-1: not one)
+  const int* wall_off;
+  WallVars* wallv;
   double* nr_mach;
   // per side (surface type 1..6): 0 no connection BC on it, 1 all of it is
   // interblock / periodic, 2 mixed (look the cell up in `surf`)
@@ -1483,6 +1486,8 @@ __device__ inline void turb_face_grads(const BlockDev& b, int d, long qU, double
   }
 }
 
+template <class B>
+__device__ inline const agx_bc_surface* get_bc_surface(const B& b, int i, int j, int k, int surf);
 __global__ void __launch_bounds__(256)
 k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1511,6 +1516,46 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
       load_area(b, d, qU, n);
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) G[3 * r + c] = grad[r][c];
+      // wall-law boundary face (procBlock.cpp:1259-1299): the wall data stored by the
+      // viscous ghost fill give the state, the viscosities and the flux itself, unless
+      // y+ < 10 switched the face to the low-Re treatment
+      const WallVars* wl = nullptr;
+      const agx_bc_surface* ws = nullptr;
+      {
+        int fc[3] = {i, j, k};
+        fc[d] += up;
+        const int nn[3] = {b.ni, b.nj, b.nk};
+        if (b.wall_off && (fc[d] == 0 || fc[d] == nn[d])) {
+          ws = get_bc_surface(b, fc[0], fc[1], fc[2], 2 * d + (fc[d] == 0 ? 1 : 2));
+          if (ws && ws->bc_type == AGX_BC_VISCOUSWALL && ws->state.is_wall_law) {
+            const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+            const int lo[3] = {ws->imin, ws->jmin, ws->kmin}, hi[3] = {ws->imax, ws->jmax, ws->kmax};
+            const WallVars* w = b.wallv + b.wall_off[ws - b.surf] +
+                                (long)(fc[d2] - lo[d2]) * (hi[d1] - lo[d1]) + (fc[d1] - lo[d1]);
+            if (!(w->yplus < 10.0)) wl = w;
+          }
+        }
+      }
+      double mut, f1, f2, f[AGX_NEQ];
+      if (wl) {
+        const double inv_sc = 1.0 / g.scaling;
+        f1 = 1.0; f2 = 1.0;
+        muf = wl->viscosity * inv_sc;
+        mut = wl->turb_eddy_visc * inv_sc;
+        // wallData::WallState wallData.cpp:299-313
+        sf[0] = wl->density;
+        for (int r = 0; r < 3; ++r) sf[1 + r] = ws->state.velocity[r];
+        sf[4] = wl->density * g.R * wl->temperature;
+        sf[5] = wl->tke; sf[6] = wl->sdr;
+        // viscousFlux::CalcWallLawFlux viscousFlux.cpp:214-247 (WallSigmaK / W: sigma_k1 /
+        // sigma_w1 of SST, 0 of the base class)
+        const double wsk = g.wilcox ? 0.0 : SST_SIGMA_K1, wsw = g.wilcox ? 0.0 : SST_SIGMA_W1;
+        f[0] = 0.0;
+        for (int r = 0; r < 3; ++r) f[1 + r] = wl->shear[r];
+        f[4] = dot3(wl->shear, ws->state.velocity) + wl->heat_flux;
+        f[5] = (wl->viscosity + wsk * wl->turb_eddy_visc) * dot3(kg, n);
+        f[6] = (wl->viscosity + wsw * wl->turb_eddy_visc) * dot3(wg, n);
+      } else {
       // state.LimitTurb; wall distance at the face by the two-cell rule
       sf[5] = fmax(sf[5], AGX_TURB_MIN);
       sf[6] = fmax(sf[6], AGX_TURB_MIN);
@@ -1518,7 +1563,6 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
       const double cD = wD / (wU + wD), cU = wU / (wU + wD);
       double wdist = cD * b.wdist[qU] + cU * b.wdist[qL];
       if (wdist < 0.0 && wdist > -1.0e-10) wdist = 0.0;
-      double mut, f1, f2;
       if (g.wilcox) kw_eddy_visc_blending(g, sf, G, mut, f1, f2);
       else sst_eddy_visc_blending(g, sf, G, kg, wg, muf, wdist, mut, f1, f2);
       // viscousFlux::CalcFlux
@@ -1536,12 +1580,12 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
       const double tg = grad[0][3] * n[0] + grad[1][3] * n[1] + grad[2][3] * n[2];
       // UseUnlimitedEddyVisc (Wilcox): the k / omega diffusion takes rho k / omega
       const double mtt = g.scaling * turb_diff_visc(g, sf, mut);
-      double f[AGX_NEQ];
       f[0] = 0.0;
       f[1] = tau[0]; f[2] = tau[1]; f[3] = tau[2];
       f[4] = dot3(tau, sf + 1) + (kk + kt) * tg;
       f[5] = (mu + turb_sigma_k(g, f1) * mtt) * dot3(kg, n);
       f[6] = (mu + turb_sigma_w(g, f1) * mtt) * dot3(wg, n);
+      }
       // this cell is the right cell of its lower face (+), the left of its upper (-)
       for (int e = 0; e < AGX_NEQ; ++e) res[e] += (up ? -1.0 : 1.0) * f[e] * n[3];
       for (int e = 0; e < 9; ++e) vgc[e] += (1.0 / 6.0) * G[e];
@@ -1820,7 +1864,13 @@ __global__ void k_bc_faces(BlockDev b, GasDev g, int viscous, int* err) {
       nr.avg_mach = b.nr_mach[2 * sn];
       nr.max_mach = b.nr_mach[2 * sn + 1];
     }
-    if (!ghost_state(g, in, bc, area, st, sf.state, layer, wd, gh, is_nr ? &nr : nullptr, nu_w)) {
+    // wall functions: the wall data of the face belong to the first layer's call
+    WallVars* wv = nullptr;
+    if (AGX_NEQ > 5 && viscous && layer == 1 && sf.state.is_wall_law && b.wall_off &&
+        b.wall_off[sn] >= 0)
+      wv = b.wallv + b.wall_off[sn] + (long)(a2 - lo[d2]) * n1 + (a1 - lo[d1]);
+    if (!ghost_state(g, in, bc, area, st, sf.state, layer, wd, gh, is_nr ? &nr : nullptr, nu_w,
+                     wv)) {
       *err = 1;
       return;
     }

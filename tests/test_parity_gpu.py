@@ -633,6 +633,46 @@ def test_turbflatplate_wilcox_parity_and_truth(agx_rans, oracle):
     sol.close()
 
 
+@pytest.mark.gpu
+def test_walllaw_parity_and_truth(agx_rans, oracle):
+    """The reference's wallLaw case (SST 2003, wall functions on the plate, BLU-SGS,
+    two blocks): HIP vs oracle per iteration -- the wall data come from a Ridder root
+    of the White-Christoph profile evaluated on the device -- and the HIP library
+    alone reproduces the reference's truth digits after 20 iterations
+    (regressionTests.py:443-445)."""
+    import json
+    from conftest import GOLDEN
+    case = golden_case("wallLaw")
+    _close(*run_pair(agx_rans, oracle, case, 3, fields=("state", "residual", "dt")))
+    with open(os.path.join(GOLDEN, "regression_truths.json")) as fh:
+        spec = json.load(fh)["wallLaw"]
+    sol = Solver(agx_rans, golden_case("wallLaw"))
+    out = sol.run(spec["iterations"])
+    for idx, (got, t) in enumerate(zip(out["norm"], spec["truth"])):
+        if idx in spec["ignore"]:
+            continue
+        assert f"{got:.4e}" == f"{t:.4e}", (idx, got, t)
+    sol.close()
+
+
+@pytest.mark.gpu
+def test_walllaw_refused_by_the_five_equation_library(agx):
+    """wallTreatment=wallLaw is a rans feature: the 5-equation library refuses the
+    surface instead of ignoring the field."""
+    from aither_amd import abi
+    surf = (abi.BcSurface * 1)()
+    surf[0].bc_type = abi.BC["viscousWall"]
+    surf[0].imin = surf[0].imax = 0
+    surf[0].jmax = surf[0].kmax = 2
+    surf[0].state.is_wall_law = 1
+    case = golden_case("uniformFlow")
+    sol = Solver(agx, case)
+    rc = agx.block_set_bcs(sol.ctx, 0, 1, surf)
+    assert rc != 0
+    assert b"wallLaw" in agx.last_error()
+    sol.close()
+
+
 RANS_WALL = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristic", 1),
              4: ("characteristic", 1), 5: ("characteristic", 1), 6: ("characteristic", 1)}
 
