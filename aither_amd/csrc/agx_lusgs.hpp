@@ -21,8 +21,8 @@
 //     the k-neighbour is the same position one plane stride away.  Values are
 //     stored in PAIRS (double2 arrays, one 16-byte load per lane: the step is
 //     bound by the number of vector-memory instructions a lone workgroup can
-//     issue, not by bytes).  The static part -- per lower face the unit normal,
-//     |A| and |A| / (centre-to-centre distance) -- is formed once; the dynamic
+//     issue, not by bytes).  The static part -- per lower face the unit normal and
+//     |A| (pairs), |A| / (centre-to-centre distance) (single) -- is formed once; the dynamic
 //     part (state, sound speed, viscous factor, right-hand side b, 1/diagonal)
 //     by k_lusgs_prepare, which transposes 32 x 32 tiles through LDS (tile
 //     diagonals are contiguous segments of the D2 plane) while it forms
@@ -47,10 +47,11 @@ enum {
   PA_S = 0,    // (rho,u) (v,w) (p,c): state + speed of sound
   PA_B = 3,    // (b0,b1) (b2,b3) (b4,1/a): right-hand side, linearSolver.cpp:370-374
   PA_X = 6,    // (x0,x1) (x2,x3) (x4,1/a): update x_
-  PA_F = 9,    // per lower face d: (nx,ny) (nz,|A|) (|A|/dist, -) at 3 * d + m; static
-  PA_COUNT = 18,
+  PA_F = 9,    // per lower face d: (nx,ny) (nz,|A|) at 2 * d + m; static
+  PA_COUNT = 15,
   D1_VF = 2 * PA_COUNT,   // single: viscous factor of the cell (spectralRadius.hpp:94-160)
-  D2_DOUBLES = 2 * PA_COUNT + 1
+  D1_AD = D1_VF + 1,      // singles, per lower face d: |A| / dist; static
+  D2_DOUBLES = 2 * PA_COUNT + 4
 };
 
 struct D2Dev {
@@ -63,6 +64,8 @@ struct D2Dev {
     return reinterpret_cast<double2*>(base + 2L * id * nd2);
   }
   __device__ __forceinline__ double* vf() const { return base + (long)D1_VF * nd2; }
+  __device__ __forceinline__ double* ad(int d) const { return base + (long)(D1_AD + d) * nd2; }
+  __device__ __forceinline__ double ld_ad(int d, long cell) const { return ad(d)[cell]; }
   __device__ __forceinline__ double2 ld_pair(int id, long cell) const { return pa(id)[cell]; }
   __device__ __forceinline__ double ld_vf(long cell) const { return vf()[cell]; }
   __device__ __forceinline__ int jlo(int de) const { return max(0, de - (Pi - 1)); }
@@ -99,6 +102,12 @@ struct KpBlk {
   }
   __device__ __forceinline__ const char* vfb() const {
     return reinterpret_cast<const char*>(base) + (size_t)D1_VF * (size_t)nd2 * 8;
+  }
+  __device__ __forceinline__ const char* adb(int d) const {
+    return reinterpret_cast<const char*>(base) + (size_t)(D1_AD + d) * (size_t)nd2 * 8;
+  }
+  __device__ __forceinline__ double ld_ad(int d, long cell) const {
+    return *reinterpret_cast<const double*>(adb(d) + cell * 8);
   }
   __device__ __forceinline__ double2 ld_pair(int id, long cell) const {
     return *reinterpret_cast<const double2*>(pab(id) + cell * 16);

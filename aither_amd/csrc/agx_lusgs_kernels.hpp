@@ -61,9 +61,9 @@ __global__ void __launch_bounds__(256) k_d2_geo(BlockDev b) {
       const double dist = dot3(v, a);
       ad = dist != 0.0 ? a[3] / dist : 0.0;
     }
-    z.pa(PA_F + 3 * d + 0)[p] = make_double2(a[0], a[1]);
-    z.pa(PA_F + 3 * d + 1)[p] = make_double2(a[2], a[3]);
-    z.pa(PA_F + 3 * d + 2)[p] = make_double2(ad, 0.0);
+    z.pa(PA_F + 2 * d + 0)[p] = make_double2(a[0], a[1]);
+    z.pa(PA_F + 2 * d + 1)[p] = make_double2(a[2], a[3]);
+    z.ad(d)[p] = ad;
   }
 }
 // x between the SoA planes and the D2 array (field download / upload only)
@@ -251,9 +251,9 @@ struct KpFace { double n[3], a, ad; };
 template <class Z>
 __device__ __forceinline__ void kp_load_face(const Z& z, int d, long p, bool viscous,
                                              KpFace& f) {
-  const double2 t0 = z.ld_pair(PA_F + 3 * d, p), t1 = z.ld_pair(PA_F + 3 * d + 1, p);
+  const double2 t0 = z.ld_pair(PA_F + 2 * d, p), t1 = z.ld_pair(PA_F + 2 * d + 1, p);
   f.n[0] = t0.x; f.n[1] = t0.y; f.n[2] = t1.x; f.a = t1.y;
-  f.ad = viscous ? z.ld_pair(PA_F + 3 * d + 2, p).x : 0.0;
+  f.ad = viscous ? z.ld_ad(d, p) : 0.0;
 }
 // a neighbour read straight from the D2 arrays (ghost cells across connection
 // boundaries, the far-side triangle of multi-sweep runs, the matrix residual)
@@ -397,10 +397,10 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
                                 FWD ? vo : (unsigned)(c.j + ng) * 16u, vo};
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          const double2 t0 = ld16(z.pab(PA_F + 3 * q) + fb[q] * 16, fo[q]);
-          const double2 t1 = ld16(z.pab(PA_F + 3 * q + 1) + fb[q] * 16, fo[q]);
+          const double2 t0 = ld16(z.pab(PA_F + 2 * q) + fb[q] * 16, fo[q]);
+          const double2 t1 = ld16(z.pab(PA_F + 2 * q + 1) + fb[q] * 16, fo[q]);
           c.f[q].n[0] = t0.x; c.f[q].n[1] = t0.y; c.f[q].n[2] = t1.x; c.f[q].a = t1.y;
-          c.f[q].ad = ld8(z.pab(PA_F + 3 * q + 2) + fb[q] * 16, fo[q]);
+          c.f[q].ad = ld8(z.adb(q) + fb[q] * 8, fo[q] >> 1);
         }
         // which sweep-side neighbours count (ImplicitLower / ImplicitUpper: physical
         // or across a connection surface); a face that does not count gets area 0
