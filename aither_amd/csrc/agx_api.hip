@@ -130,6 +130,11 @@ struct agx_ctx {
   bool fused_pending = false;
   bool use_graphs = true;    // AGX_GRAPHS=0: launch the hyperplane sweeps one by one
   hipStream_t cap_stream = nullptr;   // stream the sweep graphs are recorded on
+  // several blocks swept hyperplane by hyperplane: the blocks of a half sweep are
+  // independent (ghost x comes from the exchange before it), so their chains of
+  // launches run side by side on up to 8 branch streams
+  std::vector<hipStream_t> branch_streams;
+  std::vector<hipEvent_t> branch_events;
   int mresid_split = 1;      // bands of diagonals per XCD in k_matrix_resid_d2 (AGX_MRESID_SPLIT)
   bool have_time_n = false;  // agx_store_time_n has run (nonreflecting BCs read consVarsN)
   // agx_iterate fills the ghost cells for the NEXT call right after the update,
@@ -624,26 +629,66 @@ int lusgs_kp_variant(agx_ctx* c, Block& blk, int full) {
 constexpr int KP_MAX_DIAG = 1 << 30;
 #endif
 
-int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full) {
+static void launch_plane_sweep(agx_ctx* c, const BlockDev& b, bool forward, int full,
+                               hipStream_t st) {
+  const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
+  const int nplanes = b.ni + b.nj + b.nk - 2;
+  for (int t = 0; t < nplanes; ++t) {
+    const int p = forward ? t : nplanes - 1 - t;
+    if (forward)
+      hipLaunchKernelGGL((k_lusgs_plane<true>), grid, tb, 0, st, b, c->gas, c->sp, p, full);
+    else
+      hipLaunchKernelGGL((k_lusgs_plane<false>), grid, tb, 0, st, b, c->gas, c->sp, p, full);
+  }
+}
+
+// every block of this rank side by side (see branch_streams); false: not applicable
+// (one block, a diagonal-ordered block, graphs switched off)
+static bool plane_sweep_all_applicable(const agx_ctx* c) {
+  if (!c->use_graphs || c->blocks.size() < 2) return false;
+  for (auto& blk : c->blocks)
+    if (blk.d.d2.base || blk.d.ni + blk.d.nj + blk.d.nk - 2 < 8) return false;
+  return true;
+}
+int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full, hipStream_t st = nullptr);
+static int lusgs_sweep_all(agx_ctx* c, bool forward, int full) {
+  const size_t ns = std::min<size_t>(c->blocks.size(), 8);
+  while (c->branch_streams.size() < ns) {
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    c->branch_streams.push_back(st);
+  }
+  while (c->branch_events.size() < ns + 1) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->branch_events.push_back(ev);
+  }
+  // fork from the library's stream, one chain of hyperplane launches (the block's own
+  // graph) per branch stream, join
+  HIPCHK(hipEventRecord(c->branch_events[ns], c->stream));
+  for (size_t q = 0; q < ns; ++q)
+    HIPCHK(hipStreamWaitEvent(c->branch_streams[q], c->branch_events[ns], 0));
+  for (size_t n = 0; n < c->blocks.size(); ++n)
+    if (lusgs_sweep(c, c->blocks[n], forward, full, c->branch_streams[n % ns])) return 1;
+  for (size_t q = 0; q < ns; ++q) {
+    HIPCHK(hipEventRecord(c->branch_events[q], c->branch_streams[q]));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->branch_events[q], 0));
+  }
+  return 0;
+}
+
+int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full, hipStream_t st) {
   const BlockDev& b = blk.d;
+  if (!st) st = c->stream;
   if (!b.d2.base) {
     // One launch per hyperplane i + j + k = p: ni + nj + nk - 2 short launches per half
     // sweep, bound by launch latency.  The sequence is the same every iteration, so it is
     // captured once into a hipGraph (per direction / triangle set / value of un_is_u, the
     // one solver parameter that changes between iterations) and replayed.
-    const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
     const int nplanes = b.ni + b.nj + b.nk - 2;
-    auto launch_all = [&](hipStream_t st) {
-      for (int t = 0; t < nplanes; ++t) {
-        const int p = forward ? t : nplanes - 1 - t;
-        if (forward)
-          hipLaunchKernelGGL((k_lusgs_plane<true>), grid, tb, 0, st, b, c->gas, c->sp, p, full);
-        else
-          hipLaunchKernelGGL((k_lusgs_plane<false>), grid, tb, 0, st, b, c->gas, c->sp, p, full);
-      }
-    };
+    auto launch_all = [&](hipStream_t st) { launch_plane_sweep(c, b, forward, full, st); };
     if (!c->use_graphs || nplanes < 8) {
-      launch_all(c->stream);
+      launch_all(st);
       return 0;
     }
     hipGraphExec_t& ge = blk.sweep_graph[forward ? 1 : 0][full ? 1 : 0][c->sp.un_is_u ? 1 : 0];
@@ -658,7 +703,7 @@ int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full) {
       HIPCHK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
       HIPCHK(hipGraphDestroy(graph));
     }
-    HIPCHK(hipGraphLaunch(ge, c->stream));
+    HIPCHK(hipGraphLaunch(ge, st));
     return 0;
   }
 #if AGX_FAST
@@ -899,6 +944,8 @@ void agx_ctx_destroy(agx_ctx* c) {
   if (c->nccl) ncclCommDestroy(c->nccl);
   for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+  for (auto ev : c->branch_events) hipEventDestroy(ev);
+  for (auto st : c->branch_streams) hipStreamDestroy(st);
   delete c;
 }
 
@@ -1546,6 +1593,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
   bool swept = false;
+  if (is_lusgs_solver(c) && plane_sweep_all_applicable(c)) return lusgs_sweep_all(c, true, full);
   for (auto& blk : c->blocks) {
     BlockDev& b = blk.d;
     if (is_lusgs_solver(c)) {
@@ -1570,6 +1618,7 @@ int agx_phase_relax_backward(agx_ctx* c, int sweep) {
   if (!is_lusgs_solver(c)) return 0;
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
+  if (plane_sweep_all_applicable(c)) return lusgs_sweep_all(c, false, full);
   for (auto& blk : c->blocks) {
     if (lusgs_sweep(c, blk, false, full)) return 1;
   }

@@ -2301,7 +2301,7 @@ k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err) {
     for (int e = 0; e < AGX_NF; ++e) b.am[(long)(AGX_NF * e + e) * b.nplane + q] = m[AGX_NF * e + e];
     if (!matrix_inverse5(m)) *err = 3;
 #pragma unroll
-    for (int e = 0; e < AGX_NJ; ++e) b.aminv[(long)e * b.nplane + q] = m[e];
+    for (int e = 0; e < AGX_NJ; ++e) b.aminv[q * AGX_NJ + e] = m[e];   // (cell-major, see apply_ainv)
     double it[2] = {0.0, 0.0};
     if (AGX_NEQ > 5) {
 #pragma unroll
@@ -2310,7 +2310,7 @@ k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err) {
         b.am_t[(long)e * b.nplane + q] = at;
         if (at == 0.0) *err = 3;
         it[e] = 1.0 / at;
-        b.aminv_t[(long)e * b.nplane + q] = it[e];
+        b.aminv_t[2 * q + e] = it[e];
       }
     }
     if (sp.requires_init) {
@@ -2334,12 +2334,15 @@ k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err) {
 __device__ __forceinline__ void apply_ainv(const BlockDev& b, const SolverDev& sp, long q,
                                            const double* v, double* out) {
   if (sp.block) {
+    // the inverse is stored cell-major (25 + 2 contiguous doubles): the cells of a
+    // hyperplane lie in different rows, so every plane-major load of the sweep kernel
+    // is a cache line per lane
     double m[AGX_NJ];
 #pragma unroll
-    for (int e = 0; e < AGX_NJ; ++e) m[e] = b.aminv[(long)e * b.nplane + q];
+    for (int e = 0; e < AGX_NJ; ++e) m[e] = b.aminv[q * AGX_NJ + e];
     mat_vec5(m, v, out);
 #pragma unroll
-    for (int e = 5; e < AGX_NEQ; ++e) out[e] = b.aminv_t[(long)(e - 5) * b.nplane + q] * v[e];
+    for (int e = 5; e < AGX_NEQ; ++e) out[e] = b.aminv_t[2 * q + (e - 5)] * v[e];
   } else {
     const double ainv = b.ainv[q];
     const double ainv_t = AGX_NEQ > 5 ? b.ainv_t[q] : 0.0;

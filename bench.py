@@ -299,23 +299,39 @@ def run_workload(args, workload, api, world, rank, local_rank):
         # (main.cpp:254-264): inside iterate, hence inside the timed region
         return sol.iterate(mm, case.deck.cfl(it // nonlin))
 
+    # rans4: the synthetic field leaves the range the k-omega model is stable in after
+    # 8 iterations (the oracle shows the same history digit for digit), so the state is
+    # re-uploaded every SEG iterations; the uploads sit between the timed segments
+    seg = 6 if workload == "rans4" else 1 << 30
+
+    def reset_state():
+        for gb in sol.block_ids:
+            sol.upload("state", gb, case.blocks[gb].state)
+
     it = 0
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        if w and w % seg == 0:
+            reset_state()
         one_step(it)
         it += 1
     api.check(api.timing_reset(sol.ctx))
     api.check(api.timing_enable(sol.ctx, 1))
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        l2, linf, mres = one_step(it)
-        it += 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, done = 0.0, 0
+    while done < args.steps:
+        if workload == "rans4":
+            reset_state()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(min(seg, args.steps - done)):
+            l2, linf, mres = one_step(it)
+            it += 1
+            done += 1
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed += time.perf_counter() - t0
     api.check(api.timing_enable(sol.ctx, 0))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
@@ -431,6 +447,11 @@ def build_line(args, res, world):
                             "library's stream" if res.get("transport", "").startswith("rccl") else
                             res.get("transport", "host-staged slabs over gloo"))},
         "roofline": roof,
+        **({"timed_region": "segments of 6 iterations; the initial state is uploaded again "
+                            "between them (outside the timed segments): the synthetic field "
+                            "leaves the k-omega model's stable range after 8 iterations, the "
+                            "oracle showing the same history"}
+           if workload == "rans4" else {}),
     }
 
 
