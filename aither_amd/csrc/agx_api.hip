@@ -42,6 +42,7 @@ struct Block {
   double* slab = nullptr;
   double* d2 = nullptr;       // D2 arrays of the LU-SGS path (agx_lusgs.hpp)
   double* blockmat = nullptr; // block-matrix solvers: a_ | aInv_ | velocityGrad_ planes
+  double* sweep_rec = nullptr; // plane-by-plane sweeps: geo | dyn | rhs records (k_sweep_records)
   int* d2_tab = nullptr;      // device: dstart[Pi + Pj] | ij_of_pos[Pi * Pj]
   std::vector<int> dstart;    // host copy (halo index maps)
   // hyperplane-per-launch sweeps captured as graphs: [forward][both triangles][un_is_u]
@@ -129,6 +130,7 @@ struct agx_ctx {
   bool allow_fuse = true;    // AGX_NO_FUSE=1: separate update kernel
   bool fused_pending = false;
   bool use_graphs = true;    // AGX_GRAPHS=0: launch the hyperplane sweeps one by one
+  bool sweep_records = true; // AGX_SWEEP_RECORDS=0: the hyperplane sweeps read the plane-major arrays
   hipStream_t cap_stream = nullptr;   // stream the sweep graphs are recorded on
   // several blocks swept hyperplane by hyperplane: the blocks of a half sweep are
   // independent (ghost x comes from the exchange before it), so their chains of
@@ -651,6 +653,17 @@ static bool plane_sweep_all_applicable(const agx_ctx* c) {
   return true;
 }
 int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full, hipStream_t st = nullptr);
+// the sweep records' copy of x after an exchange (ghost cells of connection surfaces);
+// without connections the records stay current: the sweeps write both copies
+static int sweep_x_in(agx_ctx* c) {
+  if (c->conns.empty()) return 0;
+  for (auto& blk : c->blocks)
+    if (blk.d.sw_geo)
+      hipLaunchKernelGGL(k_sweep_x_in, dim3((unsigned)((blk.d.nplane + 255) / 256)), dim3(256), 0,
+                         c->stream, blk.d);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 static int lusgs_sweep_all(agx_ctx* c, bool forward, int full) {
   const size_t ns = std::min<size_t>(c->blocks.size(), 8);
   while (c->branch_streams.size() < ns) {
@@ -889,6 +902,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_LUSGS")) c->lusgs_mode = !strcmp(w, "plane") ? 0 : 1;
     if (const char* w = getenv("AGX_SPIN_LIMIT")) c->spin_limit = std::max(1, atoi(w));
     if (const char* w = getenv("AGX_GRAPHS")) c->use_graphs = atoi(w) != 0;
+    if (const char* w = getenv("AGX_SWEEP_RECORDS")) c->sweep_records = atoi(w) != 0;
     if (const char* w = getenv("AGX_MRESID_SPLIT")) c->mresid_split = std::min(64, std::max(1, atoi(w)));
   }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
@@ -907,6 +921,7 @@ void agx_ctx_destroy(agx_ctx* c) {
     if (b.slab) hipFree(b.slab);
     if (b.d2) hipFree(b.d2);
     if (b.blockmat) hipFree(b.blockmat);
+    if (b.sweep_rec) hipFree(b.sweep_rec);
     if (b.d2_tab) hipFree(b.d2_tab);
     if (b.kp_mem) hipFree(b.kp_mem);
     for (auto& g1 : b.sweep_graph) for (auto& g2 : g1) for (auto& g3 : g2)
@@ -1076,6 +1091,15 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
     d.vg = b.blockmat + (size_t)d.nplane * 2 * AGX_NJ;
     d.am_t = d.vg + (size_t)d.nplane * 9;
     d.aminv_t = d.am_t + (size_t)d.nplane * 2;
+  }
+  d.sw_geo = d.sw_dyn = d.sw_rhs = nullptr;
+  if (c->sp.implicit && is_lusgs_solver(c) && !use_d2(c) && c->sweep_records) {
+    const size_t n = (size_t)d.nplane * (SW_GEO + SW_DYN + SW_RHS);
+    HIPCHK(hipMalloc((void**)&b.sweep_rec, sizeof(double) * n));
+    HIPCHK(hipMemsetAsync(b.sweep_rec, 0, sizeof(double) * n, c->stream));
+    d.sw_geo = b.sweep_rec;
+    d.sw_dyn = d.sw_geo + (size_t)d.nplane * SW_GEO;
+    d.sw_rhs = d.sw_dyn + (size_t)d.nplane * SW_DYN;
   }
   if (use_d2(c) && std::min(d.ni, d.nj) > KP_MAX_DIAG)
     return fail("LU-SGS: a block with min(ni, nj) = %d exceeds the %d cells per diagonal "
@@ -1584,6 +1608,9 @@ int agx_phase_implicit_begin(agx_ctx* c) {
                          c->stream, planes(b.x), b.nplane);
     hipLaunchKernelGGL(k_implicit_begin, cell_grid(b, CELL_BLOCK), CELL_BLOCK, 0,
                        c->stream, b, c->gas, c->sp, c->err_dev);
+    if (b.sw_geo)
+      hipLaunchKernelGGL(k_sweep_records, dim3((unsigned)((b.nplane + 255) / 256)), dim3(256), 0,
+                         c->stream, b, c->sp);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -1593,6 +1620,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
   bool swept = false;
+  if (is_lusgs_solver(c) && sweep_x_in(c)) return 1;
   if (is_lusgs_solver(c) && plane_sweep_all_applicable(c)) return lusgs_sweep_all(c, true, full);
   for (auto& blk : c->blocks) {
     BlockDev& b = blk.d;
@@ -1618,6 +1646,7 @@ int agx_phase_relax_backward(agx_ctx* c, int sweep) {
   if (!is_lusgs_solver(c)) return 0;
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
+  if (sweep_x_in(c)) return 1;
   if (plane_sweep_all_applicable(c)) return lusgs_sweep_all(c, false, full);
   for (auto& blk : c->blocks) {
     if (lusgs_sweep(c, blk, false, full)) return 1;

@@ -55,6 +55,11 @@ struct BlockDev {
   double* am_t;
   double* aminv_t;
   double* wdist;              // wallDist_                procBlock.hpp:88
+  // hyperplane-by-hyperplane sweeps (null otherwise): cell-major records of what a sweep
+  // reads of a cell and its neighbours (see k_sweep_records) and of the right-hand side
+  double* sw_geo;
+  double* sw_dyn;
+  double* sw_rhs;
   D2Dev d2;                   // diagonal-ordered arrays of the LU-SGS path (agx_lusgs.hpp)
   const agx_bc_surface* surf; // boundaryConditions      boundaryConditions.hpp:231
   int nsurf, nsurf_i, nsurf_j, nsurf_k;
@@ -2261,6 +2266,106 @@ __device__ __forceinline__ void add_off_diag(const BlockDev& b, const GasDev& g,
   }
 }
 
+// The cells of a hyperplane i + j + k = p lie in different grid rows: read from the
+// plane-major arrays, every load of a sweep thread is a cache line of its own (~150 per
+// cell).  Before the sweeps of an iteration, what they read of a cell or of its
+// neighbours is gathered once, coalesced, into cell-major records:
+//   geo [16]: centre (3), the lower faces' unit normal and |A| (3 x 4)
+//   dyn [32]: state (<= 7, from 0), velocityGrad_ (9, from 8), eddy viscosity and f1 (17, 18),
+//             x (<= 7, from 24): written here, again after every exchange of x
+//             (k_sweep_x_in) and by the sweeps themselves beside the plane-major x
+//   rhs  [8]: the right-hand side b of the cell (k_implicit_begin)
+// so that a neighbour costs three lines instead of forty-two.
+constexpr int SW_GEO = 16, SW_DYN = 32, SW_RHS = 8, SW_X = 24;
+__global__ void __launch_bounds__(256) k_sweep_records(BlockDev b, SolverDev sp) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.nplane) return;
+  double* gq = b.sw_geo + t * SW_GEO;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) gq[r] = b.cen[r][t];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gq[3 + 4 * d + c] = b.fa[d][c][t];
+  double* dq = b.sw_dyn + t * SW_DYN;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) dq[e] = b.state[e][t];
+  if (b.vg && sp.viscous) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) dq[8 + e] = b.vg[(long)e * b.nplane + t];
+  }
+#if AGX_NEQ > 5
+  dq[17] = b.turb3[0][t];
+  dq[18] = b.turb3[1][t];
+#endif
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) dq[SW_X + e] = b.x[e][t];
+}
+// x of every cell (ghost cells just exchanged) into the records
+__global__ void __launch_bounds__(256) k_sweep_x_in(BlockDev b) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.nplane) return;
+  double* dq = b.sw_dyn + t * SW_DYN;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) dq[SW_X + e] = b.x[e][t];
+}
+// add_off_diag from the records (identical arithmetic)
+__device__ __forceinline__ void add_off_diag_rec(const BlockDev& b, const GasDev& g,
+                                                 const SolverDev& sp, int i,
+                                                 int j, int k, long q, bool lower, double sign,
+                                                 double* acc) {
+  const int c[3] = {i, j, k};
+  const int nn[3] = {b.ni, b.nj, b.nk};
+  const double* gq = b.sw_geo + q * SW_GEO;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const long s = b.stride(d);
+    bool use;
+    if (lower) {
+      use = c[d] > 0 || bc_is_connection(b, i, j, k, 2 * d + 1);
+    } else {
+      const int o[3] = {d == 0, d == 1, d == 2};
+      use = c[d] < nn[d] - 1 || bc_is_connection(b, i + o[0], j + o[1], k + o[2], 2 * d + 2);
+    }
+    if (!use) continue;
+    const long qn = lower ? q - s : q + s;
+    const double* gn = b.sw_geo + qn * SW_GEO;
+    const double* dn = b.sw_dyn + qn * SW_DYN;
+    const double* gf = lower ? gq : gn;           // the face belongs to the upper cell
+    double area[4], sn[AGX_NEQ], du[AGX_NEQ], od[AGX_NEQ];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) area[e] = gf[3 + 4 * d + e];
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) { sn[e] = dn[e]; du[e] = dn[SW_X + e]; }
+    double dist = 1.0, mu = 0.0;
+    if (sp.viscous) {
+      const double v[3] = {lower ? gq[0] - gn[0] : gn[0] - gq[0],
+                           lower ? gq[1] - gn[1] : gn[1] - gq[1],
+                           lower ? gq[2] - gn[2] : gn[2] - gq[2]};
+      dist = dot3(v, area);
+      mu = viscosity(g, temperature(g, sn));
+    }
+    const double mut_n = AGX_NEQ > 5 ? dn[17] : 0.0, f1_n = AGX_NEQ > 5 ? dn[18] : 0.0;
+    if (sp.block) {
+      double vgn[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) vgn[e] = sp.viscous ? dn[8 + e] : 0.0;
+      block_off_diagonal(g, sp.viscous != 0, sn, du, area, mu, dist, lower, vgn, od, mut_n, f1_n);
+    } else {
+      double sd[AGX_NEQ];
+      if (sp.roe_jacobian) {
+        const double* dq = b.sw_dyn + q * SW_DYN;
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) sd[e] = dq[e];
+      }
+      off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od,
+                   sp.roe_jacobian ? sd : nullptr, mut_n, f1_n);
+    }
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) acc[e] += sign * od[e];
+  }
+}
+
 // linearSolver::AddDiagonalTerms :146-175, Invert :177-188,
 // InitializeMatrixUpdate :111-144
 __global__ void __launch_bounds__(256)
@@ -2270,6 +2375,12 @@ k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err) {
   const int k = blockIdx.z;
   if (i >= b.ni || j >= b.nj) return;
   const long q = b.idx(i, j, k);
+  if (b.sw_rhs) {       // the right-hand side, cell-major, for the plane-by-plane sweeps
+    double rb[AGX_NEQ];
+    rhs_b(b, g, sp, q, rb);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) b.sw_rhs[q * SW_RHS + e] = rb[e];
+  }
   double dvt = (b.vol[q] * (1.0 + sp.zeta)) / (b.dt[q] * sp.theta);
   if (sp.dual_time_cfl > 0.0)    // specRadius_.Max(): the larger of the flow and turbulence parts
     dvt += fmax(fmax(b.specrad[q], AGX_NEQ > 5 ? b.specrad_t[q] : 0.0), 0.0) / sp.dual_time_cfl;
@@ -2375,30 +2486,52 @@ __global__ void __launch_bounds__(256) k_lusgs_plane(BlockDev b, GasDev g, Solve
   if (i < 0 || i >= b.ni) return;
   const long q = b.idx(i, j, k);
   double acc[AGX_NEQ] = {0, 0, 0, 0, 0}, out[AGX_NEQ];
+  const bool rec = b.sw_geo != nullptr;
+  auto off = [&](bool lower, double sign) {
+    if (rec) add_off_diag_rec(b, g, sp, i, j, k, q, lower, sign, acc);
+    else add_off_diag(b, g, sp, b.x, i, j, k, q, lower, sign, acc);
+  };
+  auto rhs = [&](double* rb) {
+    if (rec) {
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) rb[e] = b.sw_rhs[q * SW_RHS + e];
+    } else {
+      rhs_b(b, g, sp, q, rb);
+    }
+  };
   if (FORWARD) {
-    add_off_diag(b, g, sp, b.x, i, j, k, q, true, 1.0, acc);
-    if (full) add_off_diag(b, g, sp, b.x, i, j, k, q, false, -1.0, acc);
+    off(true, 1.0);
+    if (full) off(false, -1.0);
     double rb[AGX_NEQ];
-    rhs_b(b, g, sp, q, rb);
+    rhs(rb);
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) acc[e] = rb[e] + acc[e];
     apply_ainv(b, sp, q, acc, out);
   } else {
-    add_off_diag(b, g, sp, b.x, i, j, k, q, false, -1.0, acc);
+    off(false, -1.0);
     if (full) {
-      add_off_diag(b, g, sp, b.x, i, j, k, q, true, 1.0, acc);
+      off(true, 1.0);
       double rb[AGX_NEQ];
-      rhs_b(b, g, sp, q, rb);
+      rhs(rb);
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e) acc[e] = rb[e] + acc[e];
       apply_ainv(b, sp, q, acc, out);
     } else {
       double xo[AGX_NEQ];
-      load5(b.x, q, xo);
+      if (rec) {
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) xo[e] = b.sw_dyn[q * SW_DYN + SW_X + e];
+      } else {
+        load5(b.x, q, xo);
+      }
       apply_ainv(b, sp, q, acc, out);     // acc = -U
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e) out[e] = xo[e] + out[e];
     }
+  }
+  if (rec) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) b.sw_dyn[q * SW_DYN + SW_X + e] = out[e];
   }
   store5(b.x, q, out);
 }
