@@ -137,6 +137,13 @@ struct agx_ctx {
   // launches run side by side on up to 8 branch streams
   std::vector<hipStream_t> branch_streams;
   std::vector<hipEvent_t> branch_events;
+  // ... or, hyperplane step by step, all blocks in one launch (k_lusgs_plane_all) from a
+  // table of their BlockDev in device memory, one graph per direction / triangle set /
+  // un_is_u (AGX_SWEEP_ALL=0: the branch streams)
+  bool sweep_all_launch = true;
+  BlockDev* blocks_tab = nullptr;        // device
+  BlockDev* blocks_tab_host = nullptr;   // pinned
+  hipGraphExec_t sweep_graph_all[2][2][2] = {};
   int mresid_split = 1;      // bands of diagonals per XCD in k_matrix_resid_d2 (AGX_MRESID_SPLIT)
   bool have_time_n = false;  // agx_store_time_n has run (nonreflecting BCs read consVarsN)
   // agx_iterate fills the ghost cells for the NEXT call right after the update,
@@ -664,7 +671,58 @@ static int sweep_x_in(agx_ctx* c) {
   HIPCHK(hipGetLastError());
   return 0;
 }
+static void drop_sweep_graphs_all(agx_ctx* c) {
+  for (auto& g1 : c->sweep_graph_all) for (auto& g2 : g1) for (auto& g3 : g2)
+    if (g3) { hipGraphExecDestroy(g3); g3 = nullptr; }
+}
+static int lusgs_sweep_all_one_launch(agx_ctx* c, bool forward, int full) {
+  const size_t nb = c->blocks.size();
+  if (!c->blocks_tab) {
+    HIPCHK(hipMalloc((void**)&c->blocks_tab, sizeof(BlockDev) * nb));
+    HIPCHK(hipHostMalloc((void**)&c->blocks_tab_host, sizeof(BlockDev) * nb));
+  }
+  // the table follows the blocks (pointers that change roles, new surfaces): if it
+  // differs from what the device holds, upload it
+  bool same = true;
+  for (size_t n = 0; n < nb; ++n)
+    same = same && memcmp(&c->blocks_tab_host[n], &c->blocks[n].d, sizeof(BlockDev)) == 0;
+  if (!same) {
+    HIPCHK(hipStreamSynchronize(c->stream));      // (nobody reads the pinned copy any more)
+    for (size_t n = 0; n < nb; ++n) memcpy(&c->blocks_tab_host[n], &c->blocks[n].d, sizeof(BlockDev));
+    HIPCHK(hipMemcpyAsync(c->blocks_tab, c->blocks_tab_host, sizeof(BlockDev) * nb,
+                          hipMemcpyHostToDevice, c->stream));
+  }
+  int steps = 0;
+  unsigned gx = 1, gy = 1;
+  for (auto& blk : c->blocks) {
+    steps = std::max(steps, blk.d.ni + blk.d.nj + blk.d.nk - 2);
+    gx = std::max(gx, (unsigned)(blk.d.nj + 63) / 64);
+    gy = std::max(gy, (unsigned)(blk.d.nk + 3) / 4);
+  }
+  const dim3 tb(64, 4), grid(gx, gy, (unsigned)nb);
+  auto launch_all = [&](hipStream_t st) {
+    for (int t = 0; t < steps; ++t) {
+      if (forward)
+        hipLaunchKernelGGL((k_lusgs_plane_all<true>), grid, tb, 0, st, c->blocks_tab, c->gas, c->sp, t, full);
+      else
+        hipLaunchKernelGGL((k_lusgs_plane_all<false>), grid, tb, 0, st, c->blocks_tab, c->gas, c->sp, t, full);
+    }
+  };
+  hipGraphExec_t& ge = c->sweep_graph_all[forward ? 1 : 0][full ? 1 : 0][c->sp.un_is_u ? 1 : 0];
+  if (!ge) {
+    if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+    launch_all(c->cap_stream);
+    HIPCHK(hipStreamEndCapture(c->cap_stream, &graph));
+    HIPCHK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(graph));
+  }
+  HIPCHK(hipGraphLaunch(ge, c->stream));
+  return 0;
+}
 static int lusgs_sweep_all(agx_ctx* c, bool forward, int full) {
+  if (c->sweep_all_launch) return lusgs_sweep_all_one_launch(c, forward, full);
   const size_t ns = std::min<size_t>(c->blocks.size(), 8);
   while (c->branch_streams.size() < ns) {
     hipStream_t st;
@@ -902,6 +960,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_LUSGS")) c->lusgs_mode = !strcmp(w, "plane") ? 0 : 1;
     if (const char* w = getenv("AGX_SPIN_LIMIT")) c->spin_limit = std::max(1, atoi(w));
     if (const char* w = getenv("AGX_GRAPHS")) c->use_graphs = atoi(w) != 0;
+    if (const char* w = getenv("AGX_SWEEP_ALL")) c->sweep_all_launch = atoi(w) != 0;
     if (const char* w = getenv("AGX_SWEEP_RECORDS")) c->sweep_records = atoi(w) != 0;
     if (const char* w = getenv("AGX_MRESID_SPLIT")) c->mresid_split = std::min(64, std::max(1, atoi(w)));
   }
@@ -959,6 +1018,9 @@ void agx_ctx_destroy(agx_ctx* c) {
   if (c->nccl) ncclCommDestroy(c->nccl);
   for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+  drop_sweep_graphs_all(c);
+  if (c->blocks_tab) hipFree(c->blocks_tab);
+  if (c->blocks_tab_host) hipHostFree(c->blocks_tab_host);
   for (auto ev : c->branch_events) hipEventDestroy(ev);
   for (auto st : c->branch_streams) hipStreamDestroy(st);
   delete c;

@@ -2478,7 +2478,8 @@ __global__ void k_copy5(Planes5 dst, Planes5 src, long n) {
 // LUSGS_Backward :385-428.  Cells of a plane are mutually independent
 // (HyperplaneReorder utility.cpp:377-398); planes are launched in order.
 template <bool FORWARD>
-__global__ void __launch_bounds__(256) k_lusgs_plane(BlockDev b, GasDev g, SolverDev sp, int plane, int full) {
+__device__ __forceinline__ void lusgs_plane_cell(const BlockDev& b, const GasDev& g,
+                                                 const SolverDev& sp, int plane, int full) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y * blockDim.y + threadIdx.y;
   if (j >= b.nj || k >= b.nk) return;
@@ -2534,6 +2535,21 @@ __global__ void __launch_bounds__(256) k_lusgs_plane(BlockDev b, GasDev g, Solve
     for (int e = 0; e < AGX_NEQ; ++e) b.sw_dyn[q * SW_DYN + SW_X + e] = out[e];
   }
   store5(b.x, q, out);
+}
+template <bool FORWARD>
+__global__ void __launch_bounds__(256) k_lusgs_plane(BlockDev b, GasDev g, SolverDev sp, int plane, int full) {
+  lusgs_plane_cell<FORWARD>(b, g, sp, plane, full);
+}
+// step t of the half sweeps of ALL blocks of the rank in one launch (blockIdx.z: block;
+// the blocks of a half sweep are independent, ghost x comes from the exchange before it):
+// block n is at its hyperplane t, or nplanes_n - 1 - t going back, and idles once it is done
+template <bool FORWARD>
+__global__ void __launch_bounds__(256)
+k_lusgs_plane_all(const BlockDev* tab, GasDev g, SolverDev sp, int t, int full) {
+  const BlockDev& b = tab[blockIdx.z];
+  const int nplanes = b.ni + b.nj + b.nk - 2;
+  if (t >= nplanes) return;
+  lusgs_plane_cell<FORWARD>(b, g, sp, FORWARD ? t : nplanes - 1 - t, full);
 }
 
 }  // namespace agx
