@@ -233,6 +233,7 @@ const dim3 CELL_BLOCK(64, 4, 1);
 
 Planes5 planes(double* const* p, int n = AGX_NEQ) {
   Planes5 r;
+  r.rec = nullptr;
   for (int e = 0; e < AGX_NEQ; ++e) r.p[e] = e < n ? p[e] : nullptr;
   r.stride = 1;
   return r;
@@ -354,6 +355,8 @@ int ensure_halo_buf(agx_ctx* c, long ndoubles) {
 bool halo_in_d2(const Block& b, int what) { return what == AGX_HALO_UPDATE && b.d.d2.base; }
 Planes5 halo_planes(Block& b, int what) {
   Planes5 r;
+  // (the scatter of an exchange of x also refreshes the sweep records' copy)
+  r.rec = what == AGX_HALO_UPDATE ? b.d.sw_dyn : nullptr;
   const bool z2 = halo_in_d2(b, what);
   r.stride = z2 ? 2 : 1;     // x of the D2 path sits in pair arrays (x0,x1) (x2,x3) (x4,-)
 #if AGX_NEQ == 7
@@ -660,17 +663,6 @@ static bool plane_sweep_all_applicable(const agx_ctx* c) {
   return true;
 }
 int lusgs_sweep(agx_ctx* c, Block& blk, bool forward, int full, hipStream_t st = nullptr);
-// the sweep records' copy of x after an exchange (ghost cells of connection surfaces);
-// without connections the records stay current: the sweeps write both copies
-static int sweep_x_in(agx_ctx* c) {
-  if (c->conns.empty()) return 0;
-  for (auto& blk : c->blocks)
-    if (blk.d.sw_geo)
-      hipLaunchKernelGGL(k_sweep_x_in, dim3((unsigned)((blk.d.nplane + 255) / 256)), dim3(256), 0,
-                         c->stream, blk.d);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
 static void drop_sweep_graphs_all(agx_ctx* c) {
   for (auto& g1 : c->sweep_graph_all) for (auto& g2 : g1) for (auto& g3 : g2)
     if (g3) { hipGraphExecDestroy(g3); g3 = nullptr; }
@@ -1682,7 +1674,6 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
   bool swept = false;
-  if (is_lusgs_solver(c) && sweep_x_in(c)) return 1;
   if (is_lusgs_solver(c) && plane_sweep_all_applicable(c)) return lusgs_sweep_all(c, true, full);
   for (auto& blk : c->blocks) {
     BlockDev& b = blk.d;
@@ -1708,7 +1699,6 @@ int agx_phase_relax_backward(agx_ctx* c, int sweep) {
   if (!is_lusgs_solver(c)) return 0;
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
-  if (sweep_x_in(c)) return 1;
   if (plane_sweep_all_applicable(c)) return lusgs_sweep_all(c, false, full);
   for (auto& blk : c->blocks) {
     if (lusgs_sweep(c, blk, false, full)) return 1;

@@ -1996,7 +1996,11 @@ __global__ void k_bc_edges(BlockDev b, GasDev g, int viscous, int* err) {
 // halo exchange: multiArray3d.hpp:790-918 (SwapSliceLocal / InsertSlice) with
 // index maps precomputed on the host from GetSwapLoc
 // (boundaryConditions.cpp:3006-3181).  buf is [n][ncomp].
-struct Planes5 { double* p[AGX_NEQ]; long stride; };   // element q of plane e: p[e][q * stride]
+// element q of plane e: p[e][q * stride]; rec (scatter only, may be null): the cell-major
+// copy of x the plane-by-plane sweeps read (k_sweep_records), entry e of cell q at
+// rec[q * SW_DYN + SW_X + e]
+struct Planes5 { double* p[AGX_NEQ]; long stride; double* rec; };
+constexpr int SW_GEO = 16, SW_DYN = 32, SW_RHS = 8, SW_X = 24;
 // both sides of one local connection in one launch (blockIdx.y = side)
 struct HaloSide { Planes5 a; const long* map; long n; double* buf; };
 __global__ void k_halo_gather2(HaloSide s0, HaloSide s1) {
@@ -2013,7 +2017,11 @@ __global__ void k_halo_scatter2(HaloSide s0, HaloSide s1) {
   if (t >= s.n) return;
   const long q = s.map[t];
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) s.a.p[e][q * s.a.stride] = s.buf[e * s.n + t];
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    const double v = s.buf[e * s.n + t];
+    s.a.p[e][q * s.a.stride] = v;
+    if (s.a.rec) s.a.rec[q * SW_DYN + SW_X + e] = v;
+  }
 }
 __global__ void k_halo_gather(Planes5 a, const long* __restrict__ src, long n,
                               double* __restrict__ buf) {
@@ -2029,7 +2037,11 @@ __global__ void k_halo_scatter(Planes5 a, const long* __restrict__ dst, long n,
   if (t >= n) return;
   const long q = dst[t];
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) a.p[e][q * a.stride] = buf[e * n + t];
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    const double v = buf[e * n + t];
+    a.p[e][q * a.stride] = v;
+    if (a.rec) a.rec[q * SW_DYN + SW_X + e] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2272,42 +2284,62 @@ __device__ __forceinline__ void add_off_diag(const BlockDev& b, const GasDev& g,
 // neighbours is gathered once, coalesced, into cell-major records:
 //   geo [16]: centre (3), the lower faces' unit normal and |A| (3 x 4)
 //   dyn [32]: state (<= 7, from 0), velocityGrad_ (9, from 8), eddy viscosity and f1 (17, 18),
-//             x (<= 7, from 24): written here, again after every exchange of x
-//             (k_sweep_x_in) and by the sweeps themselves beside the plane-major x
+//             x (<= 7, from 24): written here, by the scatter of every exchange of x
+//             (Planes5::rec) and by the sweeps themselves beside the plane-major x
 //   rhs  [8]: the right-hand side b of the cell (k_implicit_begin)
 // so that a neighbour costs three lines instead of forty-two.
-constexpr int SW_GEO = 16, SW_DYN = 32, SW_RHS = 8, SW_X = 24;
 __global__ void __launch_bounds__(256) k_sweep_records(BlockDev b, SolverDev sp) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= b.nplane) return;
-  double* gq = b.sw_geo + t * SW_GEO;
+  // 256 consecutive cells per workgroup: plane-major reads (coalesced), the records of
+  // the 256 cells written as one contiguous run through LDS (row stride 33: the
+  // write-out walks consecutive words)
+  __shared__ double sh[256][SW_DYN + 1];
+  const int tid = threadIdx.x;
+  const long t0 = (long)blockIdx.x * 256, t = t0 + tid;
+  const long ncell = min(256L, b.nplane - t0);
+  if (t < b.nplane) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r) gq[r] = b.cen[r][t];
+    for (int r = 0; r < 3; ++r) sh[tid][r] = b.cen[r][t];
 #pragma unroll
-  for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < 3; ++d)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) gq[3 + 4 * d + c] = b.fa[d][c][t];
-  double* dq = b.sw_dyn + t * SW_DYN;
-#pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) dq[e] = b.state[e][t];
-  if (b.vg && sp.viscous) {
-#pragma unroll
-    for (int e = 0; e < 9; ++e) dq[8 + e] = b.vg[(long)e * b.nplane + t];
+      for (int c = 0; c < 4; ++c) sh[tid][3 + 4 * d + c] = b.fa[d][c][t];
+    sh[tid][15] = 0.0;
   }
+  __syncthreads();
+  {
+    double* out = b.sw_geo + t0 * SW_GEO;
+#pragma unroll
+    for (int m = 0; m < SW_GEO; ++m) {
+      const int idx = m * 256 + tid;
+      if (idx < ncell * SW_GEO) out[idx] = sh[idx / SW_GEO][idx % SW_GEO];
+    }
+  }
+  __syncthreads();
+  if (t < b.nplane) {
+#pragma unroll
+    for (int e = 0; e < SW_DYN; ++e) sh[tid][e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) sh[tid][e] = b.state[e][t];
+    if (b.vg && sp.viscous) {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) sh[tid][8 + e] = b.vg[(long)e * b.nplane + t];
+    }
 #if AGX_NEQ > 5
-  dq[17] = b.turb3[0][t];
-  dq[18] = b.turb3[1][t];
+    sh[tid][17] = b.turb3[0][t];
+    sh[tid][18] = b.turb3[1][t];
 #endif
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) dq[SW_X + e] = b.x[e][t];
-}
-// x of every cell (ghost cells just exchanged) into the records
-__global__ void __launch_bounds__(256) k_sweep_x_in(BlockDev b) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= b.nplane) return;
-  double* dq = b.sw_dyn + t * SW_DYN;
+    for (int e = 0; e < AGX_NEQ; ++e) sh[tid][SW_X + e] = b.x[e][t];
+  }
+  __syncthreads();
+  {
+    double* out = b.sw_dyn + t0 * SW_DYN;
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) dq[SW_X + e] = b.x[e][t];
+    for (int m = 0; m < SW_DYN; ++m) {
+      const int idx = m * 256 + tid;
+      if (idx < ncell * SW_DYN) out[idx] = sh[idx / SW_DYN][idx % SW_DYN];
+    }
+  }
 }
 // add_off_diag from the records (identical arithmetic)
 __device__ __forceinline__ void add_off_diag_rec(const BlockDev& b, const GasDev& g,
