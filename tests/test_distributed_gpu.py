@@ -36,6 +36,11 @@ DIMS = (70, 9, 8)
 
 
 def _case(kind, ranks):
+    if kind == "wallLaw":     # the reference's case: SST 2003, wall functions, BLU-SGS, 2 blocks
+        from aither_amd.case.builder import build_case
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        return build_case(os.path.join(root, "tests", "golden", "cases", kind, kind + ".inp"),
+                          ranks=ranks)
     dims = (20, 9, 8) if kind == "rans" else DIMS
     return synthetic.stacked_blocks_case(dims, nblocks=2, axis="k", stretch=1.1,
                                          ranks=ranks, **KW[kind])
@@ -65,7 +70,7 @@ def _worker(rank, port, kind, q, in_library=False):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=2)
     import aither_amd
-    agx = aither_amd.load(7 if kind == "rans" else 5)
+    agx = aither_amd.load(7 if kind in ("rans", "wallLaw") else 5)
     case = _case(kind, [0, 1])
     if in_library:   # agx_iterate drives the remote connection (host-staged slabs over gloo)
         sol = Solver(agx, case, rank=rank, exchange=DistExchange(2))
@@ -105,7 +110,8 @@ def test_rccl_transport_single_rank(agx, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,in_library", [(k, False) for k in sorted(KW)] +
-                         [("rk4", True), ("lusgs", True), ("rans", True)])
+                         [("rk4", True), ("lusgs", True), ("rans", True),
+                          ("wallLaw", False), ("wallLaw", True)])
 def test_two_ranks_on_one_gpu(oracle, kind, in_library):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
