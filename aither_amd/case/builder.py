@@ -95,11 +95,45 @@ def nondim_state(deck, gas, st):
     return out
 
 
+def cloud_states(deck, gas, path):
+    """CalcTreeFromCloud (utility.cpp:521-605): the points and nondimensional primitive
+    states of a cloud file (count, species line, then x y z rho u v w p tke omega mf...)."""
+    with open(path) as fh:
+        lines = [ln.strip() for ln in fh if ln.strip()]
+    npts = int(lines[0].split()[0])
+    species = lines[1].split()
+    if len(species) != 1:
+        raise NotImplementedError("multi-species cloud file")
+    rows = np.array([[float(t) for t in ln.split()] for ln in lines[2:2 + npts]])
+    if rows.shape != (npts, 10 + len(species)):
+        raise ValueError("cloud file: wrong number of columns")
+    a_ref, r_ref = gas.a_ref, deck.rho_ref
+    pts = rows[:, 0:3] / deck.l_ref
+    st = np.empty((npts, 7 if deck.is_rans() else 5))
+    st[:, 0] = rows[:, 3] / r_ref * rows[:, 10]
+    st[:, 1:4] = rows[:, 4:7] / a_ref
+    st[:, 4] = rows[:, 7] / (r_ref * a_ref * a_ref)
+    if deck.is_rans():
+        mu_ref = gas.visc_c1 * gas.t_ref ** 1.5 / (gas.t_ref + gas.visc_s)
+        st[:, 5] = rows[:, 8] / (a_ref * a_ref)
+        st[:, 6] = rows[:, 9] * mu_ref / (r_ref * a_ref * a_ref)
+    return pts, st
+
+
+def initial_from_cloud(deck, gas, geom, path):
+    """procBlock::InitializeStates, file branch (procBlock.cpp:287-320): every physical
+    cell takes the state of the cloud point nearest to its centre."""
+    from scipy.spatial import cKDTree
+    pts, st = cloud_states(deck, gas, path)
+    ng = geom.ng
+    cen = geom.center.a[ng:ng + geom.nk, ng:ng + geom.nj, ng:ng + geom.ni, :]
+    _, idx = cKDTree(pts).query(cen.reshape(-1, 3))
+    return st[idx].reshape(geom.nk, geom.nj, geom.ni, -1)
+
+
 def initial_primitive(deck, gas, block):
     """primitive::NondimensionalInitialize (primitive.cpp:40-64)."""
     ic = deck.ic_for_block(block)
-    if ic.get("file") is not None:
-        raise NotImplementedError("cloud-file initial conditions")
     s = nondim_state(deck, gas, State("icState", ic.params))
     prim = [1.0 * s.density, s.velocity[0], s.velocity[1], s.velocity[2], s.pressure]
     if deck.is_rans():
@@ -195,8 +229,13 @@ def build_case(inp_path, grid_dir=None, deck=None, coords=None, ranks=None):
     for b, x in enumerate(coords):
         g = _geo.BlockGeometry(x, ng)
         g.assign_ghost_geom(deck.bcs[b])
-        prim = initial_primitive(deck, gas, b)
-        st = np.zeros((g.nk + 2 * ng, g.nj + 2 * ng, g.ni + 2 * ng, len(prim)))
+        ic_file = deck.ic_for_block(b).get("file")
+        if ic_file is not None:       # (relative to the case directory, as the reference runs)
+            base = grid_dir or os.path.dirname(os.path.abspath(inp_path))
+            prim = initial_from_cloud(deck, gas, g, os.path.join(base, ic_file))
+        else:
+            prim = initial_primitive(deck, gas, b)
+        st = np.zeros((g.nk + 2 * ng, g.nj + 2 * ng, g.ni + 2 * ng, prim.shape[-1]))
         st[ng:ng + g.nk, ng:ng + g.nj, ng:ng + g.ni, :] = prim
         blocks.append(Block(g, deck.bcs[b], st, b, b, ranks[b], local_pos[b]))
         total += g.ni * g.nj * g.nk

@@ -45,7 +45,7 @@ SYNC_FIELDS = ("state", "cons_n", "cons_nm1", "update")
 
 
 def run_pair(agx, oracle, case, steps, fields=("state", "residual", "dt"),
-             resync=True):
+             resync=True, check_from=0):
     """Advance `steps` time steps with both backends and compare everything
     that crosses the boundary after every step.
 
@@ -56,7 +56,11 @@ def run_pair(agx, oracle, case, steps, fields=("state", "residual", "dt"),
     A residual is a small difference of large fluxes, so without the resync
     its error relative to its own (shrinking) magnitude grows like
     |flux| / |residual| times the state error although the state itself stays
-    within 1e-13 (see test_free_running_drift)."""
+    within 1e-13 (see test_free_running_drift).
+
+    check_from: first time step that is compared (earlier ones run, resynchronised
+    as usual, but are not asserted on) -- for cases whose first step is
+    ill-conditioned in the reference's own formulas, see the caller."""
     sg, so = Solver(agx, case), Solver(oracle, case)
     ng = case.ng
     n_hist = 0
@@ -74,6 +78,9 @@ def run_pair(agx, oracle, case, steps, fields=("state", "residual", "dt"),
             sg.l2_first = None if so.l2_first is None else so.l2_first.copy()
         sg.step(nn), so.step(nn)
         assert len(sg.history) == len(so.history)
+        if nn < check_from:
+            n_hist = len(so.history)
+            continue
         for hg, ho in zip(sg.history[n_hist:], so.history[n_hist:]):
             e = rel_err(hg["l2"][None, :], ho["l2"][None, :], nfloor)
             assert e < RTOL, ("L2 residual norm", hg["nn"], hg["mm"], e,

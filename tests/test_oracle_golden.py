@@ -3,9 +3,10 @@
 The reference's tests (testCases/regressionTests.py) run each case for a fixed
 number of iterations and compare the last line of <case>.resid with hard-coded
 normalised L2 residuals to 1 %.  The same inputs (grid + .inp, copied as data
-under tests/golden/cases) are run here through the oracle; five of the six
-cases reproduce every printed digit (5 significant figures), couette agrees to
-the reference's own 1 % tolerance.
+under tests/golden/cases) are run here through the oracle; eight cases
+reproduce every printed digit (5 significant figures), couette and
+convectingVortex agree to 1e-3 or better, inside the reference's own 1 %
+tolerance.
 """
 import json
 import os
@@ -33,4 +34,6 @@ def test_oracle_reproduces_reference_truth(oracle, name):
         assert abs(g - t) <= 0.01 * t, (name, idx, g, t)
         if spec.get("digits_exact", True):
             assert f"{g:.4e}" == f"{t:.4e}", (name, idx, g, t)
+        else:       # couette, convectingVortex: what is actually reached
+            assert abs(g - t) <= spec["rtol"] * t, (name, idx, g, t)
     sol.close()
