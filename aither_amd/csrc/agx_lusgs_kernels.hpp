@@ -126,8 +126,9 @@ k_lusgs_prepare(BlockDev b, GasDev g, SolverDev sp, int write_x) {
       if (phys) {
         double dvt = (b.vol[q] * (1.0 + sp.zeta)) / (b.dt[q] * sp.theta);
         if (sp.dual_time_cfl > 0.0) dvt += fmax(b.specrad[q], 0.0) / sp.dual_time_cfl;
+        // (the plane-major a_ is not written back: on this path nobody reads it again --
+        // 1/a goes to the D2 arrays -- and the next residual assigns it afresh)
         const double a = b.a[q] * sp.relax + dvt;
-        b.a[q] = a;
         ainv[m] = 1.0 / a;
         rhs_b(b, g, sp, q, bb[m]);
         if (sp.requires_init) {
@@ -742,7 +743,8 @@ k_update_d2(BlockDev b, GasDev g, SolverDev sp, int last_mm, NormPartial* partia
       for (int e = 0; e < AGX_NEQ; ++e) du[e] = sv[e][lj][li];
       update_prim_with_cons(g, s, du, ns);
       store5(b.state, q, ns);
-      b.a[q] = 0.0;                       // gridLevel::ResetDiagonal
+      // (gridLevel::ResetDiagonal: the inviscid residual kernels ASSIGN the scalar
+      // diagonal, so there is nothing to reset on this path)
       if (sp.bdf2 && last_mm) {           // gridLevel.cpp:425-428
         double u[AGX_NEQ];
         load5(b.consn, q, u);
