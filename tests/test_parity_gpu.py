@@ -705,6 +705,23 @@ def test_walllaw_refused_by_the_five_equation_library(agx):
     sol.close()
 
 
+@pytest.mark.gpu
+def test_plane_sweep_forms_agree_bitwise(agx_rans):
+    """The hyperplane-by-hyperplane sweeps of the 7-equation / block-matrix builds: all
+    blocks of a step in one launch reading cell-major records (default), one graph per
+    block on branch streams (AGX_SWEEP_ALL=0), plane-major loads (AGX_SWEEP_RECORDS=0)
+    and launches without graphs (AGX_GRAPHS=0) are the same arithmetic in a different
+    order of memory accesses: bit-identical states on the reference's wallLaw case
+    (two blocks, BLU-SGS with four sweeps, wall functions)."""
+    ref = None
+    for env in ({}, {"AGX_SWEEP_ALL": "0"}, {"AGX_SWEEP_RECORDS": "0"}, {"AGX_GRAPHS": "0"},
+                {"AGX_SWEEP_ALL": "0", "AGX_SWEEP_RECORDS": "0"}):
+        got = _run_with_env(agx_rans, golden_case("wallLaw"), 3, env)
+        if ref is None:
+            ref = got
+        assert np.array_equal(got, ref), env
+
+
 RANS_WALL = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristic", 1),
              4: ("characteristic", 1), 5: ("characteristic", 1), 6: ("characteristic", 1)}
 
