@@ -191,7 +191,7 @@ class InputDeck:
             bad.append("multi-species")
         if self.equation_set not in ("euler", "navierStokes", "rans"):
             bad.append(f"equationSet {self.equation_set}")
-        if self.equation_set == "rans" and self.turbulence_model not in ("sst2003",
+        if self.equation_set == "rans" and self.turbulence_model not in ("sst2003", "sstdes",
                                                                          "kOmegaWilcox2006"):
             bad.append(f"turbulenceModel {self.turbulence_model}")
         if self.thermodynamic_model != "caloricallyPerfect":

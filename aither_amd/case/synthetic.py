@@ -75,11 +75,16 @@ def make_deck(**kw):
         d.nonlinear_iterations = 4
     if d.time_integration == "explicitEuler":
         d.nonlinear_iterations = 1
+    # farfield turbulence (turbulenceIntensity, eddyViscosityRatio) of the initial state and
+    # the characteristic boundary; the reference's defaults unless given
+    turb = {}
+    if kw.get("turbulence") is not None:
+        turb = dict(turbulenceIntensity=kw["turbulence"][0], eddyViscosityRatio=kw["turbulence"][1])
     d.ics = [State("icState", dict(tag=-1, pressure=101325.0, density=1.225,
-                                   velocity=[50.0, 20.0, 10.0]))]
+                                   velocity=[50.0, 20.0, 10.0], **turb))]
     d.bc_states = [
         State("characteristic", dict(tag=1, pressure=101325.0, density=1.225,
-                                     velocity=[50.0, 20.0, 10.0])),
+                                     velocity=[50.0, 20.0, 10.0], **turb)),
         State("viscousWall", dict(tag=2)),
         State("pressureOutlet", dict(tag=3, pressure=101325.0)),
         State("viscousWall", dict(tag=4, temperature=300.0,

@@ -1034,8 +1034,9 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
 #if AGX_NEQ == 7
   if (cfg->equation_set != AGX_EQN_RANS || !cfg->is_viscous)
     return fail("the 7-equation library serves equation_set rans (viscous) only");
-  if (cfg->turbulence_model != AGX_TURB_SST2003 && cfg->turbulence_model != AGX_TURB_KW_WILCOX2006)
-    return fail("turbulence_model %d: sst2003 and kOmegaWilcox2006 are built",
+  if (cfg->turbulence_model != AGX_TURB_SST2003 && cfg->turbulence_model != AGX_TURB_KW_WILCOX2006 &&
+      cfg->turbulence_model != AGX_TURB_SST_DES)
+    return fail("turbulence_model %d: sst2003, sstdes and kOmegaWilcox2006 are built",
                 cfg->turbulence_model);
   if (cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE)
     return fail("rans: approximateRoe is not built");
@@ -1072,6 +1073,7 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
   c->cfg = *cfg;
   derive_gas(*cfg, c->gas);
   c->gas.wilcox = cfg->turbulence_model == AGX_TURB_KW_WILCOX2006 ? 1 : 0;
+  c->gas.sstdes = cfg->turbulence_model == AGX_TURB_SST_DES ? 1 : 0;
   c->gas.turb_prandtl = c->gas.wilcox ? 8.0 / 9.0 : 0.9;
   SolverDev& sp = c->sp;
   sp.kappa = cfg->kappa;

@@ -35,6 +35,7 @@ struct GasDev {
   // rans: turbulence model (0: k-omega SST 2003, 1: k-omega Wilcox 2006) and its
   // turbulent Prandtl number (0.9 / 8/9; turbulence.hpp:500, :398)
   int wilcox;
+  int sstdes;      // turbSstDes: SST 2003 whose k destruction is scaled by phi (turbulence.hpp:616-656)
   double turb_prandtl;
 };
 

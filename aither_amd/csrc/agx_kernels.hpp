@@ -1627,7 +1627,16 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
   // ---- source terms of the cell, turbKWSst::CalcTurbSrc turbulence.cpp:637-690 ----
   {
     const double inv_sc = 1.0 / g.scaling;
-    const double tke_dest = inv_sc * SST_BETA_STAR * (sc[0] * sc[5] * sc[6] * 1.0);
+    // turbSstDes::CalcTurbSrc turbulence.cpp:866-922: phi = max((1 - f2) Lt / (cdes width), 1)
+    // with width = MaxCellWidth (procBlock.cpp:5993-5995) scales the k destruction
+    double phi = 1.0, width = 1.0;
+    if (g.sstdes) {
+      width = fmax(fmax(b.wid[0][q], b.wid[1][q]), b.wid[2][q]);
+      const double cdes = sst_blend(0.78, 0.61, f1c);
+      const double lt = sqrt(sc[5]) / (SST_BETA_STAR * sc[6]) * g.scaling;
+      phi = fmax((1.0 - f2c) * lt / (cdes * width), 1.0);
+    }
+    const double tke_dest = inv_sc * SST_BETA_STAR * (sc[0] * sc[5] * sc[6] * phi);
     const double lambda = -(2.0 / 3.0) * mutc;
     const double trace = vgc[0] + vgc[4] + vgc[8];
     double ddot = 0.0;
@@ -1659,11 +1668,18 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
       res[5] -= (tke_prod - tke_dest) * vol;
       res[6] -= (omg_prod - omg_dest + omg_cd) * vol;
     }
-    const double src_sr = -2.0 * SST_BETA_STAR * sc[6] * vol * inv_sc;   // SrcSpecRad :739-747
+    double src_sr = -2.0 * SST_BETA_STAR * sc[6] * vol * inv_sc;   // SrcSpecRad :739-747
+    if (g.sstdes) {
+      // turbSstDes::SrcSpecRad :925-935: the larger diagonal entry of TurbSrcJac with beta2;
+      // it receives the cell WIDTH in the place of phi (procBlock.cpp:5993-6004)
+      const double j00 = -2.0 * SST_BETA_STAR * sc[6] * width * vol * inv_sc;
+      const double j11 = -2.0 * SST_BETA2 * sc[6] * vol * inv_sc;
+      src_sr = -1.0 * fmax(fabs(j00), fabs(j11));
+    }
     srt -= src_sr;
     diag_t -= src_sr;
     if (sp.implicit && sp.block) {     // SubtractFromTurb(TurbSrcJac), turbulence.cpp:749-770
-      b.am_t[q] -= -2.0 * SST_BETA_STAR * sc[6] * 1.0 * vol * inv_sc;
+      b.am_t[q] -= -2.0 * SST_BETA_STAR * sc[6] * phi * vol * inv_sc;
       b.am_t[b.nplane + q] -= -2.0 * beta * sc[6] * vol * inv_sc;
     }
   }

@@ -1,6 +1,7 @@
 /* aither_gfx950.h -- C-ABI of libaither_gfx950.so (5 equations: euler,
  * navierStokes) and of libaither_gfx950_rans.so (7 equations: rans with k-omega
- * SST 2003; the same sources built with -DAGX_NEQ=7, the same entry points).
+ * SST 2003, SST-DES or k-omega Wilcox 2006, low-Re walls or adiabatic wall
+ * functions; the same sources built with -DAGX_NEQ=7, the same entry points).
  *
  * MI355X (gfx950) implementation of AITHER's per-iteration hot path:
  * ghost-cell fill, face reconstruction, inviscid/viscous fluxes, time step,

@@ -1754,6 +1754,8 @@ static void sst_eddy_visc_blending(const ora_ctx *c, const double *s, const doub
 #define KW_BETA0 0.0708
 #define KW_CLIM 0.875
 static int is_wilcox(const ora_ctx *c) { return c->cfg.turbulence_model == AGX_TURB_KW_WILCOX2006; }
+/* turbSstDes (turbulence.hpp:616-656): turbKWSst whose k destruction is scaled by phi */
+static int is_sstdes(const ora_ctx *c) { return c->cfg.turbulence_model == AGX_TURB_SST_DES; }
 /* TurbPrandtlNumber: 8/9 (Wilcox), 0.9 (SST) */
 static double turb_prandtl(const ora_ctx *c) { return is_wilcox(c) ? 8.0 / 9.0 : 0.9; }
 static double sigma_k(const ora_ctx *c, double f1) {
@@ -2036,7 +2038,17 @@ static void calc_src_terms(ora_ctx *c, blk_t *b) {
                                2.0 / 3.0 * s[0] * s[5] * id;
             ddot += tau * vg[3 * cc + r];
           }
-        const double tkeDest = invScaling * SST_BETA_STAR * (s[0] * s[5] * s[6] * 1.0);
+        /* turbSstDes::CalcTurbSrc turbulence.cpp:866-922: phi = max((1 - f2) Lt / (cdes width), 1)
+         * with width = MaxCellWidth (procBlock.cpp:5993-5995) scales the k destruction */
+        double phi = 1.0, width = 1.0;
+        if (is_sstdes(c)) {
+          const double f2 = b->turb3[3 * q + 2];
+          width = fmax(fmax(b->wid[0][q], b->wid[1][q]), b->wid[2][q]);
+          const double cdes = sst_blend(0.78, 0.61, f1);
+          const double lt = sqrt(s[5]) / (SST_BETA_STAR * s[6]) * c->scaling;
+          phi = fmax((1.0 - f2) * lt / (cdes * width), 1.0);
+        }
+        const double tkeDest = invScaling * SST_BETA_STAR * (s[0] * s[5] * s[6] * phi);
         double beta, src5, src6;
         if (is_wilcox(c)) {
           /* turbKWWilcox::CalcTurbSrc turbulence.cpp:359-407 */
@@ -2064,12 +2076,19 @@ static void calc_src_terms(ora_ctx *c, blk_t *b) {
           src5 = tkeProd - tkeDest;
           src6 = omgProd - omgDest + omgCd;
         }
-        /* turbKWSst::SrcSpecRad turbulence.cpp:739-747 */
-        const double turbSpecRad = -2.0 * SST_BETA_STAR * s[6] * vol * invScaling;
+        /* turbKWSst::SrcSpecRad turbulence.cpp:739-747; turbSstDes::SrcSpecRad :925-935 takes
+         * the larger diagonal entry of TurbSrcJac with beta2 -- and receives the cell WIDTH
+         * in the place of phi (procBlock.cpp:5993-6004 hands the same variable to both) */
+        double turbSpecRad = -2.0 * SST_BETA_STAR * s[6] * vol * invScaling;
+        if (is_sstdes(c)) {
+          const double j00 = -2.0 * SST_BETA_STAR * s[6] * width * vol * invScaling;
+          const double j11 = -2.0 * SST_BETA2 * s[6] * vol * invScaling;
+          turbSpecRad = -1.0 * fmax(fabs(j00), fabs(j11));
+        }
         b->specrad_t[p] -= turbSpecRad;
         if (implicit) b->a_t[p] -= turbSpecRad;
         if (implicit && is_block(c)) {       /* SubtractFromTurb(TurbSrcJac), :749-770 */
-          b->am_t[2 * p] -= -2.0 * SST_BETA_STAR * s[6] * 1.0 * vol * invScaling;
+          b->am_t[2 * p] -= -2.0 * SST_BETA_STAR * s[6] * phi * vol * invScaling;
           b->am_t[2 * p + 1] -= -2.0 * beta * s[6] * vol * invScaling;
         }
         b->resid[NEQ * p + 5] -= src5 * vol;
@@ -2527,8 +2546,8 @@ int ora_config_set(ora_ctx *c, const agx_config *cfg) {
   if ((cfg->n_eq == 7) != (cfg->equation_set == AGX_EQN_RANS))
     return fail("n_eq = 7 goes with equation_set rans and nothing else");
   if (cfg->n_eq == 7 && cfg->turbulence_model != AGX_TURB_SST2003 &&
-      cfg->turbulence_model != AGX_TURB_KW_WILCOX2006)
-    return fail("rans: the sst2003 and kOmegaWilcox2006 models are restated");
+      cfg->turbulence_model != AGX_TURB_KW_WILCOX2006 && cfg->turbulence_model != AGX_TURB_SST_DES)
+    return fail("rans: the sst2003, sstdes and kOmegaWilcox2006 models are restated");
   if (cfg->n_eq == 7 && cfg->inv_flux_jacobian == AGX_JACOBIAN_APPROX_ROE)
     return fail("rans: approximateRoe is not restated");
   if (g_live_cfg > 0 && !c->have_cfg && cfg->n_eq != g_neq)

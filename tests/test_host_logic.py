@@ -245,3 +245,28 @@ def test_oracle_nonreflecting_uniform_flow_is_fixed_point(oracle):
         s.close()
     assert np.isfinite(moved[0]).all() and moved[0][..., 0].min() > 0.5
     assert np.abs(moved[0] - moved[1]).max() > 1e-6
+
+
+def test_sstdes_differs_from_sst_only_in_the_k_destruction(oracle):
+    """turbSstDes (turbulence.cpp:858-935) is SST 2003 with the k destruction scaled by
+    phi = max((1 - f2) Lt / (cdes width), 1): on a box whose farfield turbulence puts Lt at
+    a third of its size the first residual differs in the k equation, in many cells, and in
+    nothing else."""
+    from aither_amd.case import synthetic
+    wall = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristic", 1),
+            4: ("characteristic", 1), 5: ("characteristic", 1), 6: ("characteristic", 1)}
+    res = {}
+    for model in ("sst2003", "sstdes"):
+        case = synthetic.single_block_case(n=(9, 8, 7), stretch=1.2, bcs=wall, equation_set="rans",
+                                           turbulence_model=model, time_integration="implicitEuler",
+                                           cfl=10.0, turbulence=(0.2, 2.4e4))
+        sol = Solver(oracle, case)
+        sol.step(0)
+        res[model] = (sol.download("residual", 0), sol.download("dt", 0))
+        sol.close()
+    d = np.abs(res["sstdes"][0] - res["sst2003"][0])
+    for e in (0, 1, 2, 3, 4, 6):
+        assert d[..., e].max() == 0.0, e
+    assert (d[..., 5] > 0.0).sum() > 50
+    # more destruction, never less: the k residual (sources subtracted) only grows
+    assert np.all(res["sstdes"][0][..., 5] >= res["sst2003"][0][..., 5])

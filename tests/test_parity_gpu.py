@@ -740,6 +740,11 @@ RANS_WALL = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristi
     # diffusion, vortex-stretching beta, cross diffusion switch), scalar and block
     dict(turbulence_model="kOmegaWilcox2006", matrix_solver="lusgs", matrix_sweeps=2),
     dict(turbulence_model="kOmegaWilcox2006", matrix_solver="blusgs", inviscid_flux="ausm"),
+    # SST-DES (turbSstDes: the k destruction scaled by phi, the reference's source spectral
+    # radius with the cell width in phi's place), scalar and block
+    # (farfield turbulence chosen so that phi > 1 in most of the box: Lt ~ 0.3 of its size)
+    dict(turbulence_model="sstdes", matrix_solver="lusgs", matrix_sweeps=2, turbulence=(0.2, 2.4e4)),
+    dict(turbulence_model="sstdes", matrix_solver="blusgs", turbulence=(0.2, 2.4e4)),
 ])
 def test_rans_synthetic_parity(agx_rans, oracle, kw):
     """3-D boxes with a viscous wall: both flux functions, MUSCL and WENO, LU-SGS and
