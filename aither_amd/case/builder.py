@@ -83,8 +83,8 @@ def nondim_state(deck, gas, st):
         if treatment not in ("lowRe", "wallLaw"):
             raise NotImplementedError(f"wallTreatment {treatment}")
         if treatment == "wallLaw":
-            if not deck.is_rans() or out.is_isothermal or out.is_heat_flux:
-                raise NotImplementedError("wall functions: adiabatic walls of rans runs")
+            if not deck.is_rans():
+                raise NotImplementedError("wall functions: rans runs")
             out.is_wall_law = 1
             out.von_karman = st.get("vonKarmen", 0.41)        # inputStates.hpp:343-344
             out.wall_constant = st.get("wallConstant", 5.5)

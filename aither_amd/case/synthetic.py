@@ -80,16 +80,21 @@ def make_deck(**kw):
     turb = {}
     if kw.get("turbulence") is not None:
         turb = dict(turbulenceIntensity=kw["turbulence"][0], eddyViscosityRatio=kw["turbulence"][1])
+    # viscous walls (tags 2: adiabatic, 4: isothermal and moving, 5: constant heat flux)
+    # with wall functions when wall_treatment="wallLaw"
+    wall = {}
+    if kw.get("wall_treatment") is not None:
+        wall = dict(wallTreatment=kw["wall_treatment"])
     d.ics = [State("icState", dict(tag=-1, pressure=101325.0, density=1.225,
                                    velocity=[50.0, 20.0, 10.0], **turb))]
     d.bc_states = [
         State("characteristic", dict(tag=1, pressure=101325.0, density=1.225,
                                      velocity=[50.0, 20.0, 10.0], **turb)),
-        State("viscousWall", dict(tag=2)),
+        State("viscousWall", dict(tag=2, **wall)),
         State("pressureOutlet", dict(tag=3, pressure=101325.0)),
         State("viscousWall", dict(tag=4, temperature=300.0,
-                                  velocity=[5.0, 0.0, 0.0])),
-        State("viscousWall", dict(tag=5, heatFlux=2.0e3)),
+                                  velocity=[5.0, 0.0, 0.0], **wall)),
+        State("viscousWall", dict(tag=5, heatFlux=2.0e3, **wall)),
         State("inlet", dict(tag=6, pressure=101325.0, density=1.225,
                             velocity=[50.0, 20.0, 10.0], nonreflecting=True,
                             lengthScale=1.0)),

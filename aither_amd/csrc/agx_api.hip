@@ -1232,10 +1232,8 @@ int agx_block_set_bcs(agx_ctx* c, int id, int n, const agx_bc_surface* s) {
     if (t < AGX_BC_SLIPWALL || t > AGX_BC_PERIODIC) return fail("unknown bc type %d", t);
     if (t == AGX_BC_INTERBLOCK || t == AGX_BC_PERIODIC) n_conn[st - 1]++; else n_other[st - 1]++;
     if (t == AGX_BC_VISCOUSWALL && s[q].state.is_wall_law) {
-      // wall functions: the 7-equation library, adiabatic walls (wallLaw::AdiabaticBCs)
+      // wall functions: the 7-equation library (wallLaw::AdiabaticBCs / HeatFluxBCs / IsothermalBCs)
       if (AGX_NEQ == 5) return fail("wallTreatment=wallLaw needs the rans library");
-      if (s[q].state.is_isothermal || s[q].state.is_heat_flux)
-        return fail("wallTreatment=wallLaw: adiabatic walls only");
     }
   }
   for (int q = 0; q < 6; ++q)

@@ -767,10 +767,30 @@ struct WallVars {     // wallVars wallData.hpp:33-62, what the solver reads (12 
 struct WallLawDev {
   double von_karman, wall_dist, yplus0, beta, gamma, q, phi, yplus_white, u_star, uplus, tw, rho_w,
          mu_w, k_w, recovery, vel_tan, heat_flux, yplus_last, cp;
+  int mode;          // 0 adiabatic, 1 constant heat flux, 2 isothermal (wallLaw.cpp:31, :89, :147)
+  double t_int, p_int;
+  const GasDev* gas;
+  // wallLaw::SetWallVars wallLaw.cpp:239-246
+  __device__ void set_wall_vars(double t) {
+    tw = t;
+    rho_w = p_int / (gas->R * t);
+    mu_w = viscosity(*gas, t) * gas->scaling;
+    k_w = conductivity(*gas, t) * gas->scaling;
+  }
   __device__ double func(double yplus) {
     uplus = (wall_dist * rho_w * vel_tan) / (mu_w * yplus);
     u_star = vel_tan / uplus;
+    if (mode == 1) {
+      // HeatFluxBCs :113-124: wall temperature from Crocco-Busemann with the wall properties
+      // of the PREVIOUS evaluation (CalcWallTemperature :231-237), then SetWallVars
+      set_wall_vars(t_int + recovery * u_star * u_star * uplus * uplus /
+                                (2.0 * cp + heat_flux * mu_w / (rho_w * k_w * u_star)));
+    }
     gamma = recovery * u_star * u_star / (2.0 * cp * tw);
+    if (mode == 2) {     // IsothermalBCs :170-172, CalcHeatFlux :223-229
+      const double tmp = (t_int / tw - 1.0 + gamma * uplus * uplus) / uplus;
+      heat_flux = tmp * (rho_w * tw * k_w * u_star) / mu_w;
+    }
     beta = heat_flux * mu_w / (rho_w * tw * k_w * u_star);
     q = sqrt(beta * beta + 4.0 * gamma);
     phi = asin(-beta / q);
@@ -783,10 +803,14 @@ struct WallLawDev {
   }
 };
 __device__ __forceinline__ double sign_of(double v) { return (double)((0.0 < v) - (v < 0.0)); }
-__device__ inline void wall_law_adiabatic(const GasDev& g, const double* s, double wall_dist,
-                                          const double* n, const double* vel_wall, bool is_lower,
-                                          double von_karman, double wall_const, WallVars& wv) {
+// mode 0: wallLaw::AdiabaticBCs :31-87; 1: HeatFluxBCs :89-145 (wall_value = q_w);
+// 2: IsothermalBCs :147-200 (wall_value = T_w)
+__device__ inline void wall_law_solve(const GasDev& g, const double* s, double wall_dist,
+                                      const double* n, const double* vel_wall, bool is_lower,
+                                      double von_karman, double wall_const, int mode,
+                                      double wall_value, WallVars& wv) {
   WallLawDev w;
+  w.mode = mode; w.gas = &g; w.p_int = s[4];
   w.von_karman = von_karman; w.wall_dist = wall_dist; w.yplus0 = exp(-von_karman * wall_const);
   w.heat_flux = 0.0; w.cp = g.cp; w.yplus_last = 0.0;
   w.beta = w.gamma = w.q = w.phi = w.yplus_white = w.u_star = w.uplus = 0.0;
@@ -795,11 +819,16 @@ __device__ inline void wall_law_adiabatic(const GasDev& g, const double* s, doub
   const double vt[3] = {vel[0] - vn * n[0], vel[1] - vn * n[1], vel[2] - vn * n[2]};
   w.vel_tan = sqrt(dot3(vt, vt));
   const double t = s[4] / (s[0] * g.R);
+  w.t_int = t;
   w.recovery = pow(g.prandtl, 1.0 / 3.0);
-  w.tw = t + 0.5 * w.recovery * w.vel_tan * w.vel_tan / g.cp;
-  w.rho_w = s[4] / (g.R * w.tw);
-  w.mu_w = viscosity(g, w.tw) * g.scaling;
-  w.k_w = conductivity(g, w.tw) * g.scaling;
+  if (mode == 0) {          // wall temperature from Crocco-Busemann, adiabatic
+    w.set_wall_vars(t + 0.5 * w.recovery * w.vel_tan * w.vel_tan / g.cp);
+  } else if (mode == 1) {   // guess: wall temperature equals interior temperature
+    w.heat_flux = wall_value;
+    w.set_wall_vars(t);
+  } else {
+    w.set_wall_vars(wall_value);
+  }
   {   // FindRoot(func, 1.0e1, 1.0e4, 1.0e-8)
     double x1 = 1.0e1, x2 = 1.0e4;
     double f1 = w.func(x1), f2 = w.func(x2);
@@ -821,7 +850,7 @@ __device__ inline void wall_law_adiabatic(const GasDev& g, const double* s, doub
     }
   }
   wv.yplus = w.yplus_last;
-  wv.heat_flux = 0.0;
+  wv.heat_flux = w.heat_flux;    // 0, q_w, or the last evaluation's Crocco-Busemann flux
   // CalcTurbVars with EddyVisc, wallLaw.cpp:243-279
   const double dyw = 2.0 * w.yplus_white * w.von_karman * sqrt(w.gamma) / w.q *
                      sqrt(fmax(1.0 - (2.0 * w.gamma * w.uplus - w.beta) *
@@ -868,32 +897,51 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
     }
     case AGX_BC_VISCOUSWALL: {
       for (int q = 0; q < 3; ++q) gh[1 + q] = 2.0 * d.velocity[q] - in[1 + q];
+      // ghostStates.cpp:144-260: per thermal wall type the low-Re ghost density, or -- with
+      // wall functions -- the wall law first, then the ghost density it implies; k and omega
+      // at the wall from the wall law unless y+ < 10 switches the face back to low-Re
+      bool low_re = true;
+      WallVars loc;
+      WallVars& w = wv ? *wv : loc;
+      const bool wl = AGX_NEQ > 5 && d.is_wall_law;
       if (d.is_isothermal) {
-        const double tg = 2.0 * d.wall_temperature - temperature(g, in);
+        double tg = 2.0 * d.wall_temperature - temperature(g, in);
+        if (wl) {
+          wall_law_solve(g, in, wall_dist, n, d.velocity, surf % 2 == 1, d.von_karman,
+                         d.wall_constant, 2, d.wall_temperature, w);
+          low_re = w.yplus < 10.0;
+          if (!low_re) {
+            // the wall law's heat flux with the turbulent conductivity (the eddy viscosity
+            // is not zero at the wall), 2 x wall distance as gradient length :161-172
+            const double kappa = conductivity(g, w.temperature) +
+                                 w.turb_eddy_visc * g.cp / g.turb_prandtl;
+            tg = d.wall_temperature - w.heat_flux / kappa * 2.0 * wall_dist;
+          }
+        }
         gh[0] = gh[4] / (g.R * tg);
       } else if (d.is_heat_flux) {
         // low-Re constant heat flux wall, ghostStates.cpp:228-242: the gradient
         // length is twice the wall distance of the wall-adjacent cell
         const double t = temperature(g, in);
-        const double tg = t - d.wall_heat_flux / conductivity(g, t) * 2.0 * wall_dist;
+        double tg = t - d.wall_heat_flux / conductivity(g, t) * 2.0 * wall_dist;
+        if (wl) {
+          wall_law_solve(g, in, wall_dist, n, d.velocity, surf % 2 == 1, d.von_karman,
+                         d.wall_constant, 1, d.wall_heat_flux, w);
+          low_re = w.yplus < 10.0;
+          if (!low_re) tg = 2.0 * w.temperature - t;      // :213-219
+        }
         gh[0] = gh[4] / (g.R * tg);
-      }
-      // wall functions (adiabatic, ghostStates.cpp:245-259): k and omega at the wall from
-      // the wall law unless y+ < 10 switches the face back to the low-Re treatment
-      bool low_re = true;
-      if (AGX_NEQ > 5 && d.is_wall_law) {
-        WallVars loc;
-        WallVars& w = wv ? *wv : loc;
-        wall_law_adiabatic(g, in, wall_dist, n, d.velocity, surf % 2 == 1, d.von_karman,
-                           d.wall_constant, w);
+      } else if (wl) {
+        wall_law_solve(g, in, wall_dist, n, d.velocity, surf % 2 == 1, d.von_karman,
+                       d.wall_constant, 0, 0.0, w);
         low_re = w.yplus < 10.0;
-        if (!low_re) {
-          gh[AGX_NEQ - 2] = 2.0 * w.tke - in[AGX_NEQ - 2];
-          gh[AGX_NEQ - 1] = 2.0 * w.sdr - in[AGX_NEQ - 1];
-          if (layer > 1) {
-            gh[AGX_NEQ - 2] = layer * gh[AGX_NEQ - 2] - w.tke;
-            gh[AGX_NEQ - 1] = layer * gh[AGX_NEQ - 1] - w.sdr;
-          }
+      }
+      if (wl && !low_re) {
+        gh[AGX_NEQ - 2] = 2.0 * w.tke - in[AGX_NEQ - 2];
+        gh[AGX_NEQ - 1] = 2.0 * w.sdr - in[AGX_NEQ - 1];
+        if (layer > 1) {
+          gh[AGX_NEQ - 2] = layer * gh[AGX_NEQ - 2] - w.tke;
+          gh[AGX_NEQ - 1] = layer * gh[AGX_NEQ - 1] - w.sdr;
         }
       }
       if (AGX_NEQ > 5 && low_re) {

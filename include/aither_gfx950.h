@@ -1,7 +1,6 @@
 /* aither_gfx950.h -- C-ABI of libaither_gfx950.so (5 equations: euler,
  * navierStokes) and of libaither_gfx950_rans.so (7 equations: rans with k-omega
- * SST 2003, SST-DES or k-omega Wilcox 2006, low-Re walls or adiabatic wall
- * functions; the same sources built with -DAGX_NEQ=7, the same entry points).
+ * SST 2003, SST-DES or k-omega Wilcox 2006, low-Re walls or wall functions; the same sources built with -DAGX_NEQ=7, the same entry points).
  *
  * MI355X (gfx950) implementation of AITHER's per-iteration hot path:
  * ghost-cell fill, face reconstruction, inviscid/viscous fluxes, time step,
@@ -174,7 +173,7 @@ typedef struct agx_bc_state {
    * turbulenceIntensity and eddyViscosityRatio; read by rans runs only */
   double turb_intensity, eddy_visc_ratio;
   /* viscousWall(wallTreatment=wallLaw): von Karman constant and wall constant
-   * (inputStates.hpp:343-345); rans library, adiabatic walls */
+   * (inputStates.hpp:343-345); rans library; adiabatic, isothermal or heat-flux wall */
   double von_karman, wall_constant;
   int32_t is_wall_law, pad2_;
 } agx_bc_state;

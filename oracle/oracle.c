@@ -616,6 +616,7 @@ static void extrap_hold(const double *bnd, double factor, const double *in,
 /* GetGhostState ghostStates.cpp:62-689 (laminar, low-Re walls, reflecting
  * inlet/outlet) */
 static int is_wilcox_fwd(const ora_ctx *c) { return c->cfg.turbulence_model == AGX_TURB_KW_WILCOX2006; }
+static double turb_prandtl_fwd(const ora_ctx *c) { return is_wilcox_fwd(c) ? 8.0 / 9.0 : 0.9; }
 /* ---- wall functions: wallLaw::AdiabaticBCs wallLaw.cpp:30-77 with its helpers
  * (:182-289) and FindRoot (Ridder, utility.hpp:130-184).  The function whose root is
  * sought has side effects: what is kept afterwards belongs to its LAST evaluation. */
@@ -624,14 +625,36 @@ typedef struct {
   const double *state;
   double vonKarmen, wallDist, yplus0, beta, gamma, q, phi, yplusWhite, uStar, uplus, tW, rhoW,
          muW, mutW, kW, recoveryFactor, velTanMag, heatFlux, yplus_last;
+  int mode;        /* 0 adiabatic, 1 constant heat flux, 2 isothermal (wallLaw.cpp:31, :89, :147) */
+  double tInt;     /* temperature of the interior state */
 } wall_law;
+/* wallLaw::SetWallVars wallLaw.cpp:239-246 */
+static void wl_set_wall_vars(wall_law *w, double tW) {
+  const ora_ctx *c = w->c;
+  w->tW = tW;
+  w->rhoW = w->state[4] / ((0.0 + 1.0 * c->cfg.gas.gas_constant) * tW);
+  w->muW = viscosity(c, tW) * c->scaling;
+  w->kW = conductivity(c, tW) * c->scaling;
+}
 static double sign_of(double v) { return (double)((0.0 < v) - (v < 0.0)); }
 static double wl_func(wall_law *w, double yplus) {
   const ora_ctx *c = w->c;
   /* CalcVelocities, UpdateGamma, UpdateConstants, CalcYplusWhite, CalcYplusRoot */
   w->uplus = (w->wallDist * w->rhoW * w->velTanMag) / (w->muW * yplus);
   w->uStar = w->velTanMag / w->uplus;
+  if (w->mode == 1) {
+    /* HeatFluxBCs :113-124: wall temperature from Crocco-Busemann with the wall properties
+     * of the PREVIOUS evaluation (CalcWallTemperature :231-237), then SetWallVars */
+    const double tNew = w->tInt + w->recoveryFactor * w->uStar * w->uStar * w->uplus * w->uplus /
+                                      (2.0 * c->cp + w->heatFlux * w->muW / (w->rhoW * w->kW * w->uStar));
+    wl_set_wall_vars(w, tNew);
+  }
   w->gamma = w->recoveryFactor * w->uStar * w->uStar / (2.0 * c->cp * w->tW);
+  if (w->mode == 2) {
+    /* IsothermalBCs :170-172, CalcHeatFlux :223-229 */
+    const double tmp = (w->tInt / w->tW - 1.0 + w->gamma * w->uplus * w->uplus) / w->uplus;
+    w->heatFlux = tmp * (w->rhoW * w->tW * w->kW * w->uStar) / w->muW;
+  }
   w->beta = w->heatFlux * w->muW / (w->rhoW * w->tW * w->kW * w->uStar);
   w->q = sqrt(w->beta * w->beta + 4.0 * w->gamma);
   w->phi = asin(-w->beta / w->q);
@@ -661,11 +684,24 @@ static void wl_find_root(wall_law *w, double x1, double x2, double tol) {
     if (fabs(x2 - x1) <= tol) return;
   }
 }
+static void wall_law_solve(const ora_ctx *c, const double *state, double wallDist,
+                           const double *normArea, const double *velWall, int isLower,
+                           double vonKarmen, double wallConst, int mode, double wallValue,
+                           wall_vars *wv);
 static void wall_law_adiabatic(const ora_ctx *c, const double *state, double wallDist,
                                const double *normArea, const double *velWall, int isLower,
                                double vonKarmen, double wallConst, wall_vars *wv) {
+  wall_law_solve(c, state, wallDist, normArea, velWall, isLower, vonKarmen, wallConst, 0, 0.0, wv);
+}
+/* mode 0: wallLaw::AdiabaticBCs :31-87; 1: HeatFluxBCs :89-145 (wallValue = q_w);
+ * 2: IsothermalBCs :147-200 (wallValue = T_w) */
+static void wall_law_solve(const ora_ctx *c, const double *state, double wallDist,
+                           const double *normArea, const double *velWall, int isLower,
+                           double vonKarmen, double wallConst, int mode, double wallValue,
+                           wall_vars *wv) {
   wall_law w;
   memset(&w, 0, sizeof w);
+  w.mode = mode;
   w.c = c; w.state = state; w.vonKarmen = vonKarmen; w.wallDist = wallDist;
   w.yplus0 = exp(-vonKarmen * wallConst);
   w.heatFlux = 0.0;
@@ -675,16 +711,19 @@ static void wall_law_adiabatic(const ora_ctx *c, const double *state, double wal
                             vel[2] - vn * normArea[2]};
   w.velTanMag = mag3(velTan);
   const double t = temperature(c, state);
+  w.tInt = t;
   w.recoveryFactor = pow(c->prandtl, 1.0 / 3.0);
-  const double tW = t + 0.5 * w.recoveryFactor * w.velTanMag * w.velTanMag / c->cp;
-  /* SetWallVars */
-  w.tW = tW;
-  w.rhoW = state[4] / ((0.0 + 1.0 * c->cfg.gas.gas_constant) * tW);
-  w.muW = viscosity(c, tW) * c->scaling;
-  w.kW = conductivity(c, tW) * c->scaling;
+  if (mode == 0) {         /* wall temperature from Crocco-Busemann, adiabatic */
+    wl_set_wall_vars(&w, t + 0.5 * w.recoveryFactor * w.velTanMag * w.velTanMag / c->cp);
+  } else if (mode == 1) {  /* guess: wall temperature equals interior temperature */
+    w.heatFlux = wallValue;
+    wl_set_wall_vars(&w, t);
+  } else {
+    wl_set_wall_vars(&w, wallValue);
+  }
   wl_find_root(&w, 1.0e1, 1.0e4, 1.0e-8);
   wv->yplus = w.yplus_last;
-  wv->heat_flux = 0.0;
+  wv->heat_flux = w.heatFlux;          /* 0, q_w, or the last evaluation's Crocco-Busemann flux */
   /* CalcTurbVars with EddyVisc, wallLaw.cpp:243-279 */
   {
     const double dYplusWhite =
@@ -759,37 +798,55 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
   } else if (bc == AGX_BC_VISCOUSWALL) {
     for (int q = 0; q < 3; ++q)
       ghost[1 + q] = 2.0 * d->velocity[q] - interior[1 + q];
+    /* ghostStates.cpp:144-260: per thermal wall type the low-Re ghost density, or -- with
+     * wall functions -- the wall law first, then the ghost density it implies; k and omega
+     * at the wall from the wall law unless y+ < 10 switches the face back to low-Re */
+    const double R = 0.0 + 1.0 * c->cfg.gas.gas_constant;
+    int lowRe = 1;
+    wall_vars loc;
+    wall_vars *w = wv ? wv : &loc;
     if (d->is_isothermal) {
-      const double tGhost = 2.0 * d->wall_temperature - temperature(c, interior);
+      const double tWall = d->wall_temperature;
+      double tGhost = 2.0 * tWall - temperature(c, interior);
+      if (d->is_wall_law) {
+        wall_law_solve(c, interior, wallDist, n, d->velocity, isLower, d->von_karman,
+                       d->wall_constant, 2, tWall, w);
+        lowRe = w->yplus < 10.0;                     /* wallVars::SwitchToLowRe */
+        if (!lowRe) {
+          /* the wall law's heat flux with the turbulent conductivity (the eddy viscosity is
+           * not zero at the wall), 2 x wall distance as gradient length :161-172 */
+          const double kappa = conductivity(c, w->temperature) +
+                               w->turb_eddy_visc * c->cp / turb_prandtl_fwd(c);
+          tGhost = tWall - w->heat_flux / kappa * 2.0 * wallDist;
+        }
+      }
       /* idealGas::DensityTP eos.cpp:111-115, MixtureGasConstant */
-      const double R = 0.0 + 1.0 * c->cfg.gas.gas_constant;
       const double rho = ghost[4] / (R * tGhost);
       ghost[0] = rho * (interior[0] / interior[0]);
     } else if (d->is_heat_flux) {
       /* low-Re constant heat flux wall, ghostStates.cpp:228-242 */
       const double t = temperature(c, interior);
       const double kappa = conductivity(c, t);
-      const double tGhost = t - d->wall_heat_flux / kappa * 2.0 * wallDist;
-      const double R = 0.0 + 1.0 * c->cfg.gas.gas_constant;
+      double tGhost = t - d->wall_heat_flux / kappa * 2.0 * wallDist;
+      if (d->is_wall_law) {
+        wall_law_solve(c, interior, wallDist, n, d->velocity, isLower, d->von_karman,
+                       d->wall_constant, 1, d->wall_heat_flux, w);
+        lowRe = w->yplus < 10.0;
+        if (!lowRe) tGhost = 2.0 * w->temperature - t;      /* :213-219 */
+      }
       const double rho = ghost[4] / (R * tGhost);
       ghost[0] = rho * (interior[0] / interior[0]);
-    }
-    /* wall functions (adiabatic, ghostStates.cpp:245-259): the wall law gives k and
-     * omega at the wall unless y+ < 10 switches the face back to the low-Re treatment */
-    int lowRe = 1;
-    if (d->is_wall_law) {
-      wall_vars loc;
-      wall_vars *w = wv ? wv : &loc;
+    } else if (d->is_wall_law) {
       wall_law_adiabatic(c, interior, wallDist, n, d->velocity, isLower, d->von_karman,
                          d->wall_constant, w);
-      lowRe = w->yplus < 10.0;                       /* wallVars::SwitchToLowRe */
-      if (rans && !lowRe) {
-        ghost[5] = 2.0 * w->tke - interior[5];
-        ghost[6] = 2.0 * w->sdr - interior[6];
-        if (layer > 1) {
-          ghost[5] = layer * ghost[5] - w->tke;
-          ghost[6] = layer * ghost[6] - w->sdr;
-        }
+      lowRe = w->yplus < 10.0;
+    }
+    if (d->is_wall_law && rans && !lowRe) {
+      ghost[5] = 2.0 * w->tke - interior[5];
+      ghost[6] = 2.0 * w->sdr - interior[6];
+      if (layer > 1) {
+        ghost[5] = layer * ghost[5] - w->tke;
+        ghost[6] = layer * ghost[6] - w->sdr;
       }
     }
     if (rans && lowRe) {

@@ -270,3 +270,26 @@ def test_sstdes_differs_from_sst_only_in_the_k_destruction(oracle):
     assert (d[..., 5] > 0.0).sum() > 50
     # more destruction, never less: the k residual (sources subtracted) only grows
     assert np.all(res["sstdes"][0][..., 5] >= res["sst2003"][0][..., 5])
+
+
+@pytest.mark.parametrize("tag", [2, 4, 5])
+def test_wall_functions_are_active_on_every_thermal_wall_type(oracle, tag):
+    """Adiabatic (2), isothermal moving (4) and constant heat flux (5) walls with
+    wallTreatment=wallLaw: the first residual differs from the low-Re wall's in the momentum
+    and turbulence equations and stays finite (y+ of the box's wall cells is far above 10)."""
+    from aither_amd.case import synthetic
+    wall = {3: ("viscousWall", tag), 1: ("characteristic", 1), 2: ("characteristic", 1),
+            4: ("characteristic", 1), 5: ("characteristic", 1), 6: ("characteristic", 1)}
+    res = {}
+    for wt in (None, "wallLaw"):
+        case = synthetic.single_block_case(n=(9, 8, 7), stretch=1.2, bcs=wall, equation_set="rans",
+                                           turbulence_model="sst2003",
+                                           time_integration="implicitEuler", cfl=10.0,
+                                           wall_treatment=wt)
+        sol = Solver(oracle, case)
+        sol.step(0)
+        res[wt] = sol.download("residual", 0)
+        sol.close()
+    assert np.isfinite(res["wallLaw"]).all()
+    d = np.abs(res[None] - res["wallLaw"]).reshape(-1, 7).max(axis=0)
+    assert np.all(d[[1, 2, 3, 5, 6]] > 0.0), d

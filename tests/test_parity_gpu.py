@@ -722,6 +722,23 @@ def test_plane_sweep_forms_agree_bitwise(agx_rans):
         assert np.array_equal(got, ref), env
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,solver", [(2, "lusgs"), (4, "lusgs"), (5, "lusgs"),
+                                        (4, "blusgs"), (5, "blusgs")])
+def test_rans_wall_function_variants_parity(agx_rans, oracle, tag, solver):
+    """Wall functions on an adiabatic (tag 2), an isothermal moving (4) and a constant
+    heat flux wall (5): wallLaw::AdiabaticBCs / IsothermalBCs / HeatFluxBCs solved per wall
+    face on the device, the ghost density each implies, the wall-law flux.  (Only the
+    adiabatic law has a reference truth -- wallLaw; the other two are HIP vs oracle.)"""
+    wall = {3: ("viscousWall", tag), 1: ("characteristic", 1), 2: ("characteristic", 1),
+            4: ("characteristic", 1), 5: ("characteristic", 1), 6: ("characteristic", 1)}
+    case = synthetic.single_block_case(n=(9, 8, 7), stretch=1.2, bcs=wall, equation_set="rans",
+                                       turbulence_model="sst2003", matrix_solver=solver,
+                                       time_integration="implicitEuler", cfl=10.0,
+                                       wall_treatment="wallLaw")
+    _close(*run_pair(agx_rans, oracle, case, 3))
+
+
 RANS_WALL = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristic", 1),
              4: ("characteristic", 1), 5: ("characteristic", 1), 6: ("characteristic", 1)}
 
