@@ -131,6 +131,7 @@ struct agx_ctx {
   bool fused_pending = false;
   bool use_graphs = true;    // AGX_GRAPHS=0: launch the hyperplane sweeps one by one
   bool sweep_records = true; // AGX_SWEEP_RECORDS=0: the hyperplane sweeps read the plane-major arrays
+  bool sweep_three = true;   // AGX_SWEEP_THREE=0: one lane per cell in the hyperplane sweeps
   hipStream_t cap_stream = nullptr;   // stream the sweep graphs are recorded on
   // several blocks swept hyperplane by hyperplane: the blocks of a half sweep are
   // independent (ghost x comes from the exchange before it), so their chains of
@@ -643,14 +644,23 @@ constexpr int KP_MAX_DIAG = 1 << 30;
 
 static void launch_plane_sweep(agx_ctx* c, const BlockDev& b, bool forward, int full,
                                hipStream_t st) {
-  const dim3 tb(64, 4), grid((b.nj + 63) / 64, (b.nk + 3) / 4);
+  // with the cell-major records: three lanes per cell (k_lusgs_plane3), 21 cells per wave row
+  const bool three = b.sw_geo != nullptr && c->sweep_three;
+  const dim3 tb(64, 4), grid(three ? (b.nj + PL3_CELLS - 1) / PL3_CELLS : (b.nj + 63) / 64,
+                             (b.nk + 3) / 4);
   const int nplanes = b.ni + b.nj + b.nk - 2;
   for (int t = 0; t < nplanes; ++t) {
     const int p = forward ? t : nplanes - 1 - t;
-    if (forward)
+    if (three) {
+      if (forward)
+        hipLaunchKernelGGL((k_lusgs_plane3<true>), grid, tb, 0, st, b, c->gas, c->sp, p, full);
+      else
+        hipLaunchKernelGGL((k_lusgs_plane3<false>), grid, tb, 0, st, b, c->gas, c->sp, p, full);
+    } else if (forward) {
       hipLaunchKernelGGL((k_lusgs_plane<true>), grid, tb, 0, st, b, c->gas, c->sp, p, full);
-    else
+    } else {
       hipLaunchKernelGGL((k_lusgs_plane<false>), grid, tb, 0, st, b, c->gas, c->sp, p, full);
+    }
   }
 }
 
@@ -686,14 +696,24 @@ static int lusgs_sweep_all_one_launch(agx_ctx* c, bool forward, int full) {
   }
   int steps = 0;
   unsigned gx = 1, gy = 1;
+  bool three = c->sweep_three;
+  for (auto& blk : c->blocks) three = three && blk.d.sw_geo != nullptr;
   for (auto& blk : c->blocks) {
     steps = std::max(steps, blk.d.ni + blk.d.nj + blk.d.nk - 2);
-    gx = std::max(gx, (unsigned)(blk.d.nj + 63) / 64);
+    gx = std::max(gx, three ? (unsigned)(blk.d.nj + PL3_CELLS - 1) / PL3_CELLS
+                            : (unsigned)(blk.d.nj + 63) / 64);
     gy = std::max(gy, (unsigned)(blk.d.nk + 3) / 4);
   }
   const dim3 tb(64, 4), grid(gx, gy, (unsigned)nb);
   auto launch_all = [&](hipStream_t st) {
     for (int t = 0; t < steps; ++t) {
+      if (three) {
+        if (forward)
+          hipLaunchKernelGGL((k_lusgs_plane_all3<true>), grid, tb, 0, st, c->blocks_tab, c->gas, c->sp, t, full);
+        else
+          hipLaunchKernelGGL((k_lusgs_plane_all3<false>), grid, tb, 0, st, c->blocks_tab, c->gas, c->sp, t, full);
+        continue;
+      }
       if (forward)
         hipLaunchKernelGGL((k_lusgs_plane_all<true>), grid, tb, 0, st, c->blocks_tab, c->gas, c->sp, t, full);
       else
@@ -953,6 +973,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_SPIN_LIMIT")) c->spin_limit = std::max(1, atoi(w));
     if (const char* w = getenv("AGX_GRAPHS")) c->use_graphs = atoi(w) != 0;
     if (const char* w = getenv("AGX_SWEEP_ALL")) c->sweep_all_launch = atoi(w) != 0;
+    if (const char* w = getenv("AGX_SWEEP_THREE")) c->sweep_three = atoi(w) != 0;
     if (const char* w = getenv("AGX_SWEEP_RECORDS")) c->sweep_records = atoi(w) != 0;
     if (const char* w = getenv("AGX_MRESID_SPLIT")) c->mresid_split = std::min(64, std::max(1, atoi(w)));
   }

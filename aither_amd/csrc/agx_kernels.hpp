@@ -2357,58 +2357,67 @@ __global__ void __launch_bounds__(256) k_sweep_records(BlockDev b, SolverDev sp)
     }
   }
 }
-// add_off_diag from the records (identical arithmetic)
+// one direction of add_off_diag, from the records (identical arithmetic): the
+// off-diagonal term of the lower / upper d-neighbour of cell q into od; false: the
+// neighbour does not count (physical boundary)
+__device__ __forceinline__ bool off_diag_rec_dir(const BlockDev& b, const GasDev& g,
+                                                 const SolverDev& sp, int i, int j, int k,
+                                                 long q, bool lower, int d, double* od) {
+  const int c[3] = {i, j, k};
+  const int nn[3] = {b.ni, b.nj, b.nk};
+  const double* gq = b.sw_geo + q * SW_GEO;
+  const long s = b.stride(d);
+  bool use;
+  if (lower) {
+    use = c[d] > 0 || bc_is_connection(b, i, j, k, 2 * d + 1);
+  } else {
+    const int o[3] = {d == 0, d == 1, d == 2};
+    use = c[d] < nn[d] - 1 || bc_is_connection(b, i + o[0], j + o[1], k + o[2], 2 * d + 2);
+  }
+  if (!use) return false;
+  const long qn = lower ? q - s : q + s;
+  const double* gn = b.sw_geo + qn * SW_GEO;
+  const double* dn = b.sw_dyn + qn * SW_DYN;
+  const double* gf = lower ? gq : gn;           // the face belongs to the upper cell
+  double area[4], sn[AGX_NEQ], du[AGX_NEQ];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) area[e] = gf[3 + 4 * d + e];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) { sn[e] = dn[e]; du[e] = dn[SW_X + e]; }
+  double dist = 1.0, mu = 0.0;
+  if (sp.viscous) {
+    const double v[3] = {lower ? gq[0] - gn[0] : gn[0] - gq[0],
+                         lower ? gq[1] - gn[1] : gn[1] - gq[1],
+                         lower ? gq[2] - gn[2] : gn[2] - gq[2]};
+    dist = dot3(v, area);
+    mu = viscosity(g, temperature(g, sn));
+  }
+  const double mut_n = AGX_NEQ > 5 ? dn[17] : 0.0, f1_n = AGX_NEQ > 5 ? dn[18] : 0.0;
+  if (sp.block) {
+    double vgn[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) vgn[e] = sp.viscous ? dn[8 + e] : 0.0;
+    block_off_diagonal(g, sp.viscous != 0, sn, du, area, mu, dist, lower, vgn, od, mut_n, f1_n);
+  } else {
+    double sd[AGX_NEQ];
+    if (sp.roe_jacobian) {
+      const double* dq = b.sw_dyn + q * SW_DYN;
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) sd[e] = dq[e];
+    }
+    off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od,
+                 sp.roe_jacobian ? sd : nullptr, mut_n, f1_n);
+  }
+  return true;
+}
 __device__ __forceinline__ void add_off_diag_rec(const BlockDev& b, const GasDev& g,
                                                  const SolverDev& sp, int i,
                                                  int j, int k, long q, bool lower, double sign,
                                                  double* acc) {
-  const int c[3] = {i, j, k};
-  const int nn[3] = {b.ni, b.nj, b.nk};
-  const double* gq = b.sw_geo + q * SW_GEO;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    const long s = b.stride(d);
-    bool use;
-    if (lower) {
-      use = c[d] > 0 || bc_is_connection(b, i, j, k, 2 * d + 1);
-    } else {
-      const int o[3] = {d == 0, d == 1, d == 2};
-      use = c[d] < nn[d] - 1 || bc_is_connection(b, i + o[0], j + o[1], k + o[2], 2 * d + 2);
-    }
-    if (!use) continue;
-    const long qn = lower ? q - s : q + s;
-    const double* gn = b.sw_geo + qn * SW_GEO;
-    const double* dn = b.sw_dyn + qn * SW_DYN;
-    const double* gf = lower ? gq : gn;           // the face belongs to the upper cell
-    double area[4], sn[AGX_NEQ], du[AGX_NEQ], od[AGX_NEQ];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) area[e] = gf[3 + 4 * d + e];
-#pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) { sn[e] = dn[e]; du[e] = dn[SW_X + e]; }
-    double dist = 1.0, mu = 0.0;
-    if (sp.viscous) {
-      const double v[3] = {lower ? gq[0] - gn[0] : gn[0] - gq[0],
-                           lower ? gq[1] - gn[1] : gn[1] - gq[1],
-                           lower ? gq[2] - gn[2] : gn[2] - gq[2]};
-      dist = dot3(v, area);
-      mu = viscosity(g, temperature(g, sn));
-    }
-    const double mut_n = AGX_NEQ > 5 ? dn[17] : 0.0, f1_n = AGX_NEQ > 5 ? dn[18] : 0.0;
-    if (sp.block) {
-      double vgn[9];
-#pragma unroll
-      for (int e = 0; e < 9; ++e) vgn[e] = sp.viscous ? dn[8 + e] : 0.0;
-      block_off_diagonal(g, sp.viscous != 0, sn, du, area, mu, dist, lower, vgn, od, mut_n, f1_n);
-    } else {
-      double sd[AGX_NEQ];
-      if (sp.roe_jacobian) {
-        const double* dq = b.sw_dyn + q * SW_DYN;
-#pragma unroll
-        for (int e = 0; e < AGX_NEQ; ++e) sd[e] = dq[e];
-      }
-      off_diagonal(g, sp.viscous, sn, du, area, mu, dist, lower, od,
-                   sp.roe_jacobian ? sd : nullptr, mut_n, f1_n);
-    }
+    double od[AGX_NEQ];
+    if (!off_diag_rec_dir(b, g, sp, i, j, k, q, lower, d, od)) continue;
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) acc[e] += sign * od[e];
   }
@@ -2588,6 +2597,81 @@ template <bool FORWARD>
 __global__ void __launch_bounds__(256) k_lusgs_plane(BlockDev b, GasDev g, SolverDev sp, int plane, int full) {
   lusgs_plane_cell<FORWARD>(b, g, sp, plane, full);
 }
+// The same step with THREE lanes per cell (records only): lane 3c + d of a wave forms the
+// off-diagonal terms of direction d of cell c -- the long part of the step, three of them
+// in a row per thread otherwise -- the lane of d = 0 adds them up in the order of the
+// one-lane form (lower i, j, k, then upper i, j, k), applies the inverse and stores.
+// 21 cells per wave row (lane 63 idles): grid.x = ceil(nj / 21).
+constexpr int PL3_CELLS = 21;
+template <bool FORWARD>
+__device__ __forceinline__ void lusgs_plane_cell3(const BlockDev& b, const GasDev& g,
+                                                  const SolverDev& sp, int plane, int full) {
+  const int lane = threadIdx.x;
+  const int c = lane / 3, d = lane - 3 * c;
+  const int j = blockIdx.x * PL3_CELLS + c;
+  const int k = blockIdx.y * blockDim.y + threadIdx.y;
+  const int i = plane - j - k;
+  const bool active = c < PL3_CELLS && j < b.nj && k < b.nk && i >= 0 && i < b.ni;
+  const long q = active ? b.idx(i, j, k) : 0;
+  // first the side the sweep comes from, then (both triangles) the other one
+  double v1[AGX_NEQ], v2[AGX_NEQ];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) { v1[e] = 0.0; v2[e] = 0.0; }
+  if (active) {
+    double od[AGX_NEQ];
+    if (off_diag_rec_dir(b, g, sp, i, j, k, q, FORWARD, d, od)) {
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) v1[e] = (FORWARD ? 1.0 : -1.0) * od[e];
+    }
+    if (full && off_diag_rec_dir(b, g, sp, i, j, k, q, !FORWARD, d, od)) {
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) v2[e] = (FORWARD ? -1.0 : 1.0) * od[e];
+    }
+  }
+  double acc[AGX_NEQ];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    const double a1 = __shfl_down(v1[e], 1, 64), a2 = __shfl_down(v1[e], 2, 64);
+    acc[e] = ((0.0 + v1[e]) + a1) + a2;
+  }
+  if (full) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      const double a1 = __shfl_down(v2[e], 1, 64), a2 = __shfl_down(v2[e], 2, 64);
+      acc[e] = ((acc[e] + v2[e]) + a1) + a2;
+    }
+  }
+  if (!active || d != 0) return;
+  double out[AGX_NEQ];
+  if (FORWARD || full) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) acc[e] = b.sw_rhs[q * SW_RHS + e] + acc[e];
+    apply_ainv(b, sp, q, acc, out);
+  } else {
+    double xo[AGX_NEQ];
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) xo[e] = b.sw_dyn[q * SW_DYN + SW_X + e];
+    apply_ainv(b, sp, q, acc, out);     // acc = -U
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) out[e] = xo[e] + out[e];
+  }
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) b.sw_dyn[q * SW_DYN + SW_X + e] = out[e];
+  store5(b.x, q, out);
+}
+template <bool FORWARD>
+__global__ void __launch_bounds__(256) k_lusgs_plane3(BlockDev b, GasDev g, SolverDev sp, int plane, int full) {
+  lusgs_plane_cell3<FORWARD>(b, g, sp, plane, full);
+}
+template <bool FORWARD>
+__global__ void __launch_bounds__(256)
+k_lusgs_plane_all3(const BlockDev* tab, GasDev g, SolverDev sp, int t, int full) {
+  const BlockDev& b = tab[blockIdx.z];
+  const int nplanes = b.ni + b.nj + b.nk - 2;
+  if (t >= nplanes) return;
+  lusgs_plane_cell3<FORWARD>(b, g, sp, FORWARD ? t : nplanes - 1 - t, full);
+}
+
 // step t of the half sweeps of ALL blocks of the rank in one launch (blockIdx.z: block;
 // the blocks of a half sweep are independent, ghost x comes from the exchange before it):
 // block n is at its hyperplane t, or nplanes_n - 1 - t going back, and idles once it is done

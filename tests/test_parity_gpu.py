@@ -708,13 +708,15 @@ def test_walllaw_refused_by_the_five_equation_library(agx):
 @pytest.mark.gpu
 def test_plane_sweep_forms_agree_bitwise(agx_rans):
     """The hyperplane-by-hyperplane sweeps of the 7-equation / block-matrix builds: all
-    blocks of a step in one launch reading cell-major records (default), one graph per
-    block on branch streams (AGX_SWEEP_ALL=0), plane-major loads (AGX_SWEEP_RECORDS=0)
-    and launches without graphs (AGX_GRAPHS=0) are the same arithmetic in a different
-    order of memory accesses: bit-identical states on the reference's wallLaw case
+    blocks of a step in one launch reading cell-major records with three lanes per cell
+    (default), one lane per cell (AGX_SWEEP_THREE=0), one graph per block on branch
+    streams (AGX_SWEEP_ALL=0), plane-major loads (AGX_SWEEP_RECORDS=0) and launches
+    without graphs (AGX_GRAPHS=0) are the same arithmetic in a different order of memory
+    accesses: bit-identical states on the reference's wallLaw case
     (two blocks, BLU-SGS with four sweeps, wall functions)."""
     ref = None
     for env in ({}, {"AGX_SWEEP_ALL": "0"}, {"AGX_SWEEP_RECORDS": "0"}, {"AGX_GRAPHS": "0"},
+                {"AGX_SWEEP_THREE": "0"}, {"AGX_SWEEP_THREE": "0", "AGX_SWEEP_ALL": "0"},
                 {"AGX_SWEEP_ALL": "0", "AGX_SWEEP_RECORDS": "0"}):
         got = _run_with_env(agx_rans, golden_case("wallLaw"), 3, env)
         if ref is None:
