@@ -1040,6 +1040,10 @@ void agx_ctx_destroy(agx_ctx* c) {
 }
 
 int agx_ctx_set_stream(agx_ctx* c, void* s) {
+  // at any time: what was queued on the old stream (set-up memsets, a previous iteration)
+  // is finished before work is issued on the new one
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
   c->stream = (hipStream_t)s;
   return 0;
 }

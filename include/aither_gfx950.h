@@ -215,7 +215,8 @@ const char *agx_version(void);
 /* rank: this process's rank in the job (matches agx_connection.rank[]) */
 int agx_ctx_create(int device, int rank, agx_ctx **out);
 void agx_ctx_destroy(agx_ctx *ctx);
-/* run all library work on this hipStream_t (NULL = default stream) */
+/* run all library work on this hipStream_t (NULL = default stream); may be called at any
+ * time: the stream used so far is drained first */
 int agx_ctx_set_stream(agx_ctx *ctx, void *hip_stream);
 int agx_config_set(agx_ctx *ctx, const agx_config *cfg);
 

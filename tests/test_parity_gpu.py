@@ -3,6 +3,7 @@
 Run on a real MI355X:  python -m pytest tests -m gpu
 Tolerance: 1e-10 relative (fp64), stated in parity_utils.RTOL.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -739,6 +740,49 @@ def test_rans_wall_function_variants_parity(agx_rans, oracle, tag, solver):
                                        time_integration="implicitEuler", cfl=10.0,
                                        wall_treatment="wallLaw")
     _close(*run_pair(agx_rans, oracle, case, 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lib", ["agx", "rans"])
+def test_user_stream_and_stream_change(agx, agx_rans, lib):
+    """agx_ctx_set_stream: the whole iteration on a stream of the caller (given at set-up),
+    and a change of stream between two iterations, give the states of the default stream
+    bit for bit (5-equation LU-SGS on the diagonal-ordered path; wallLaw on the
+    hyperplane graphs)."""
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def new_stream():
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(st)) == 0
+        return st
+    api = agx if lib == "agx" else agx_rans
+    if lib == "agx":
+        wall = {3: ("viscousWall", 2), 1: ("characteristic", 1),
+                2: ("characteristic", 1), 4: ("characteristic", 1)}
+        make = lambda: synthetic.single_block_case(n=(21, 19, 17), stretch=1.1, bcs=wall,
+                                                   equation_set="navierStokes",
+                                                   time_integration="implicitEuler",
+                                                   matrix_solver="lusgs", cfl=5.0)
+    else:
+        make = lambda: golden_case("wallLaw")
+    g = make().ng
+    ref = Solver(api, make())
+    for nn in range(3):
+        ref.step(nn)
+    want = ref.download("state", 0)[g:-g, g:-g, g:-g]
+    ref.close()
+    s1, s2 = new_stream(), new_stream()
+    sol = Solver(api, make(), stream=s1.value)
+    sol.step(0)
+    api.check(api.ctx_set_stream(sol.ctx, s2), "set_stream")
+    sol.step(1)
+    api.check(api.ctx_set_stream(sol.ctx, ctypes.c_void_p(0)), "set_stream")
+    sol.step(2)
+    got = sol.download("state", 0)[g:-g, g:-g, g:-g]
+    sol.close()
+    for st in (s1, s2):
+        hip.hipStreamDestroy(st)
+    assert np.array_equal(got, want)
 
 
 RANS_WALL = {3: ("viscousWall", 2), 1: ("characteristic", 1), 2: ("characteristic", 1),
