@@ -118,6 +118,8 @@ struct agx_ctx {
   int* err_host = nullptr;              // pinned
   double* halo_buf = nullptr;
   long halo_cap = 0;
+  double* stage_buf = nullptr;   // AoS staging of uploads / downloads (stage_buffer)
+  size_t stage_cap = 0;
   bool use_gather = false;   // AGX_KERNEL=gather: one-thread-per-cell gather kernel
   bool use_tile = true;      // AGX_KERNEL=tile (default) | march
   int num_cu = 256;          // persistent workgroups of the tile kernel
@@ -241,32 +243,43 @@ Planes5 planes(double* const* p, int n = AGX_NEQ) {
 }
 
 // upload an AoS host array (dims (ci,cj,ck) incl. gsrc ghosts, ncomp per cell)
+// device staging of the AoS <-> SoA conversions: one buffer per context that only grows
+// (an output step downloads a dozen fields per block; no hipMalloc / hipFree per call)
+static int stage_buffer(agx_ctx* c, size_t doubles, double** out) {
+  if (doubles > c->stage_cap) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->stage_buf) HIPCHK(hipFree(c->stage_buf));
+    c->stage_buf = nullptr; c->stage_cap = 0;
+    HIPCHK(hipMalloc((void**)&c->stage_buf, sizeof(double) * doubles));
+    c->stage_cap = doubles;
+  }
+  *out = c->stage_buf;
+  return 0;
+}
 int upload_aos(agx_ctx* c, Block& b, const double* host, double* const* dst,
                int ncomp, int ci, int cj, int ck, int gsrc) {
   const long n = (long)ci * cj * ck;
   double* tmp = nullptr;
-  HIPCHK(hipMalloc((void**)&tmp, sizeof(double) * n * ncomp));
+  if (stage_buffer(c, (size_t)n * ncomp, &tmp)) return 1;
   HIPCHK(hipMemcpyAsync(tmp, host, sizeof(double) * n * ncomp,
                         hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_aos_to_soa, dim3((n + 255) / 256), dim3(256), 0,
                      c->stream, tmp, planes(dst, ncomp), ncomp, ci, cj, ck, gsrc, b.d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipFree(tmp));
   return 0;
 }
 int download_aos(agx_ctx* c, Block& b, double* host, double* const* src,
                  int ncomp, int ci, int cj, int ck, int gsrc) {
   const long n = (long)ci * cj * ck;
   double* tmp = nullptr;
-  HIPCHK(hipMalloc((void**)&tmp, sizeof(double) * n * ncomp));
+  if (stage_buffer(c, (size_t)n * ncomp, &tmp)) return 1;
   hipLaunchKernelGGL(k_soa_to_aos, dim3((n + 255) / 256), dim3(256), 0,
                      c->stream, tmp, planes(src, ncomp), ncomp, ci, cj, ck, gsrc, b.d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(host, tmp, sizeof(double) * n * ncomp,
                         hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipFree(tmp));
   return 0;
 }
 
@@ -1020,6 +1033,7 @@ void agx_ctx_destroy(agx_ctx* c) {
   if (c->err_dev) hipFree(c->err_dev);
   if (c->err_host) hipHostFree(c->err_host);
   if (c->halo_buf) hipFree(c->halo_buf);
+  if (c->stage_buf) hipFree(c->stage_buf);
   for (auto& r : c->remote) {
     if (r.send) hipFree(r.send);
     if (r.recv) hipFree(r.recv);
@@ -1501,7 +1515,7 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
     // cell-centre gradients: formed on demand into a temporary (an output path)
     const long ncell = (long)b.d.ni * b.d.nj * b.d.nk;
     double* tmp = nullptr;
-    HIPCHK(hipMalloc((void**)&tmp, sizeof(double) * 18 * ncell));
+    if (stage_buffer(c, (size_t)18 * ncell, &tmp)) return 1;
     hipLaunchKernelGGL(k_cell_grads, cell_grid(b.d, CELL_BLOCK), CELL_BLOCK, 0, c->stream, b.d,
                        c->gas, tmp);
     HIPCHK(hipGetLastError());
@@ -1511,7 +1525,6 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
     HIPCHK(hipMemcpy2DAsync(out, sizeof(double) * nc, tmp + off, sizeof(double) * 18,
                             sizeof(double) * nc, ncell, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipFree(tmp));
     return 0;
   }
   if (field == AGX_FIELD_TEMPERATURE || field == AGX_FIELD_VISCOSITY) {
