@@ -146,6 +146,7 @@ struct agx_ctx {
   bool sweep_all_launch = true;
   BlockDev* blocks_tab = nullptr;        // device
   BlockDev* blocks_tab_host = nullptr;   // pinned
+  size_t blocks_tab_n = 0;
   hipGraphExec_t sweep_graph_all[2][2][2] = {};
   int mresid_split = 1;      // bands of diagonals per XCD in k_matrix_resid_d2 (AGX_MRESID_SPLIT)
   bool have_time_n = false;  // agx_store_time_n has run (nonreflecting BCs read consVarsN)
@@ -692,9 +693,18 @@ static void drop_sweep_graphs_all(agx_ctx* c) {
 }
 static int lusgs_sweep_all_one_launch(agx_ctx* c, bool forward, int full) {
   const size_t nb = c->blocks.size();
+  if (c->blocks_tab && c->blocks_tab_n != nb) {      // (blocks were added since)
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(c->blocks_tab));
+    HIPCHK(hipHostFree(c->blocks_tab_host));
+    c->blocks_tab = nullptr; c->blocks_tab_host = nullptr;
+    drop_sweep_graphs_all(c);                        // (their grids cover nb blocks)
+  }
   if (!c->blocks_tab) {
     HIPCHK(hipMalloc((void**)&c->blocks_tab, sizeof(BlockDev) * nb));
     HIPCHK(hipHostMalloc((void**)&c->blocks_tab_host, sizeof(BlockDev) * nb));
+    memset(c->blocks_tab_host, 0, sizeof(BlockDev) * nb);
+    c->blocks_tab_n = nb;
   }
   // the table follows the blocks (pointers that change roles, new surfaces): if it
   // differs from what the device holds, upload it
