@@ -105,7 +105,7 @@ struct agx_ctx {
                   double *hsend = nullptr, *hrecv = nullptr; };
   std::vector<Remote> remote;
   std::vector<agx_slab> slabs;
-  struct NormRecord { double l2[8]; double mres, linf; int32_t block, i, j, k, eqn, pad;
+  struct NormRecord { double l2[8]; double mres, linf; int32_t block, i, j, k, eqn, status;
                       double fill[3]; };     // 128 bytes
   NormRecord* rec_dev = nullptr;        // [1 + nranks] device (RCCL)
   NormRecord* rec_host = nullptr;       // [1 + nranks] pinned
@@ -1073,6 +1073,11 @@ int agx_ctx_set_stream(agx_ctx* c, void* s) {
 }
 
 int agx_config_set(agx_ctx* c, const agx_config* cfg) {
+  // allocations (block-matrix planes, sweep records, D2 arrays) and the captured sweep
+  // graphs are decided from the configuration a block was created under
+  if (!c->blocks.empty())
+    return fail("agx_config_set: the configuration is fixed after the first "
+                "agx_block_create (make a new context for another scheme)");
   if (cfg->n_eq != AGX_NEQ)
     return fail("n_eq = %d: this library is built for %d equations (5: euler / "
                 "navierStokes, libaither_gfx950.so; 7: rans, libaither_gfx950_rans.so)",
@@ -1954,8 +1959,10 @@ int agx_halo_exchange(agx_ctx* c, int what) {
 
 namespace {
 // main.cpp:254-264 over the exchange: every rank ends up with the global norms
+// `status`: this rank's local result of the iteration; a failure anywhere makes every
+// rank return failure (the collectives are reached by all ranks either way)
 int reduce_over_ranks(agx_ctx* c, double* l2, agx_linf* linf, double* matrix_resid,
-                      const double* l2_in) {
+                      const double* l2_in, int status) {
   typedef agx_ctx::NormRecord Rec;
   const int nr = c->ex.nranks;
   Rec& mine = c->rec_host[0];
@@ -1964,6 +1971,7 @@ int reduce_over_ranks(agx_ctx* c, double* l2, agx_linf* linf, double* matrix_res
   mine.mres = *matrix_resid;
   mine.linf = linf->linf; mine.block = linf->block; mine.i = linf->i; mine.j = linf->j;
   mine.k = linf->k; mine.eqn = linf->eqn;
+  mine.status = status;
   Rec* all = c->rec_host + 1;
   if (c->ex.host_buffers) {
     if (c->ex.allgather(c->ex.user, &mine, all, (int64_t)sizeof(Rec), c->stream))
@@ -1976,6 +1984,12 @@ int reduce_over_ranks(agx_ctx* c, double* l2, agx_linf* linf, double* matrix_res
                           c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
+  for (int r = 0; r < nr; ++r)
+    if (all[r].status != 0) {
+      if (status != 0) return status;      // g_err holds this rank's own message
+      return fail("agx_iterate: rank %d failed (status %d); its agx_last_error has the cause",
+                  r, all[r].status);
+    }
   // fold in rank order: the same result on every rank
   double mres = 0.0;
   for (int e = 0; e < AGX_NEQ; ++e) l2[e] = l2_in[e];
@@ -2001,6 +2015,27 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
                 "(agx_set_exchange / agx_rccl_exchange_create) or the phase API");
   double l2_in[AGX_NEQ];
   for (int e = 0; e < AGX_NEQ; ++e) l2_in[e] = l2[e];
+  // A local failure (a singular block, the sweep's spin limit, a refused phase) must not
+  // leave the other ranks waiting in a collective: from the first failure on the compute
+  // phases are skipped, the exchanges and the final all-gather are still reached, and the
+  // status word of the norm record fails the call on every rank.
+  int st = 0;
+  char first_err[sizeof g_err] = "";
+  const bool collective = c->have_ex && c->ex.nranks > 1;
+  auto phase = [&](int r) {
+    if (r && !st) { st = r; memcpy(first_err, g_err, sizeof g_err); }
+  };
+#define AGX_PHASE(call) do { if (!st) phase(call); } while (0)
+  // an exchange runs even after a local failure when other ranks take part in it; a
+  // failure of the exchange itself cannot be hidden from the peers and ends the call
+#define AGX_XCHG(what)                                              \
+  do {                                                              \
+    if (!st || collective) {                                        \
+      const int r_ = agx_halo_exchange(c, what);                    \
+      if (r_ && st) { memcpy(g_err, first_err, sizeof g_err); return st; } \
+      if (r_) return r_;                                            \
+    }                                                               \
+  } while (0)
   // gridLevel::GetBoundaryConditions gridLevel.cpp:287-319 (already done behind the
   // previous call's norm read-back unless something touched the state since)
   if (!c->ghosts_prefilled && fill_ghosts(c)) return 1;
@@ -2008,38 +2043,41 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
   struct Scope { agx_ctx* c; ~Scope() { c->in_iterate = false; } } scope{c};
   c->in_iterate = true;
   // gridLevel::CalcResidual :372-400 + CalcTimeStep :240-247
-  if (agx_phase_residual(c, mm, cfl)) return 1;
+  AGX_PHASE(agx_phase_residual(c, mm, cfl));
   *matrix_resid = 0.0;
-  int rc;
   if (c->sp.implicit) {
     // gridLevel::SwapEddyViscAndGradients gridLevel.cpp:386-388 (read by the
     // off-diagonal terms of the block-matrix solvers only)
     if (c->sp.block && c->sp.viscous && !c->conns.empty()) {
-      if (agx_halo_exchange(c, AGX_HALO_VELGRAD_A)) return 1;
-      if (agx_halo_exchange(c, AGX_HALO_VELGRAD_B)) return 1;
+      AGX_XCHG(AGX_HALO_VELGRAD_A);
+      AGX_XCHG(AGX_HALO_VELGRAD_B);
     }
     // ... and of eddyViscosity_, f1_, f2_ (SwapTurbVars :389-392), rans
-    if (AGX_NEQ == 7 && !c->conns.empty() && agx_halo_exchange(c, AGX_HALO_TURB)) return 1;
+    if (AGX_NEQ == 7 && !c->conns.empty()) AGX_XCHG(AGX_HALO_TURB);
     // mgSolution::ImplicitUpdate :209-244; lusgs::Relax linearSolver.cpp:430-470;
     // dplur::Relax :509-535
-    if (agx_phase_implicit_begin(c)) return 1;
+    AGX_PHASE(agx_phase_implicit_begin(c));
     for (int s = 0; s < c->cfg.matrix_sweeps; ++s) {
-      if (agx_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
-      if (agx_phase_relax_forward(c, s)) return 1;
+      AGX_XCHG(AGX_HALO_UPDATE);
+      AGX_PHASE(agx_phase_relax_forward(c, s));
       if (is_lusgs_solver(c)) {
-        if (agx_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
-        if (agx_phase_relax_backward(c, s)) return 1;
+        AGX_XCHG(AGX_HALO_UPDATE);
+        AGX_PHASE(agx_phase_relax_backward(c, s));
       }
     }
-    if (agx_halo_exchange(c, AGX_HALO_UPDATE)) return 1;
-    if (agx_phase_matrix_residual(c, matrix_resid)) return 1;
-    rc = agx_phase_implicit_update(c, mm, l2, linf);
+    AGX_XCHG(AGX_HALO_UPDATE);
+    AGX_PHASE(agx_phase_matrix_residual(c, matrix_resid));
+    AGX_PHASE(agx_phase_implicit_update(c, mm, l2, linf));
   } else {
-    rc = agx_phase_explicit_update(c, mm, l2, linf);
+    AGX_PHASE(agx_phase_explicit_update(c, mm, l2, linf));
   }
-  if (rc) return rc;
-  if (c->have_ex) return reduce_over_ranks(c, l2, linf, matrix_resid, l2_in);
-  return 0;
+#undef AGX_PHASE
+#undef AGX_XCHG
+  // the explicit update queues the next call's ghost fill -- an exchange -- behind its norms
+  if (st && collective && !c->sp.implicit && c->eager_ghosts) (void)fill_ghosts(c);
+  if (st) memcpy(g_err, first_err, sizeof g_err);
+  if (c->have_ex) return reduce_over_ranks(c, l2, linf, matrix_resid, l2_in, st);
+  return st;
 }
 
 // ---- measurement ------------------------------------------------------------

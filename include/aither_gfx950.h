@@ -30,6 +30,14 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The libraries are built with -fvisibility=hidden: only the agx_* entry points below are
+ * exported.  libaither_gfx950.so (5 equations) and libaither_gfx950_rans.so (7 equations)
+ * are the SAME sources compiled for two state layouts, so their internals must never bind
+ * to each other; with the internals hidden the two can share a process (each dlopen'ed
+ * RTLD_LOCAL and called through dlsym, since both export the same agx_* names). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ---- enumerations (resolved once from the reference's std::string input
  *      options, include/input.hpp:48-291) -------------------------------- */
@@ -50,7 +58,9 @@ enum { AGX_JACOBIAN_RUSANOV = 0,
 enum { AGX_VISC_RECON_CENTRAL = 0,
        AGX_VISC_RECON_CENTRAL_4TH = 1 };      /* reconstruction.hpp:315-379 */
 enum { AGX_TURB_NONE = 0, AGX_TURB_SST2003 = 1, AGX_TURB_KW_WILCOX2006 = 2,
-       AGX_TURB_SST_DES = 3, AGX_TURB_WALE = 4 };  /* turbulence.hpp */
+       AGX_TURB_SST_DES = 3,
+       AGX_TURB_WALE = 4 /* named for completeness: agx_config_set REFUSES it (not built) */
+     };                                       /* turbulence.hpp */
 
 /* boundary condition types, ghostStates.cpp:62-689 */
 enum { AGX_BC_SLIPWALL = 0, AGX_BC_VISCOUSWALL = 1, AGX_BC_CHARACTERISTIC = 2,
@@ -88,7 +98,8 @@ enum { AGX_HALO_STATE = 0, AGX_HALO_UPDATE = 1,
        AGX_HALO_VELGRAD_A = 2, AGX_HALO_VELGRAD_B = 3,
        /* rans: eddyViscosity_, f1_, f2_ of the cells across connection surfaces
         * (SwapEddyViscAndGradients / SwapTurbVars, gridLevel.cpp:386-392); read by the
-        * off-diagonal terms.  Oracle only so far. */
+        * off-diagonal terms.  libaither_gfx950_rans.so (and the oracle); the 5-equation
+        * library refuses it. */
        AGX_HALO_TURB = 4 };
 
 /* ---- plain-old-data descriptors --------------------------------------- */
@@ -340,6 +351,9 @@ int agx_timing_get(agx_ctx *ctx, int group, double *avg_ms, int64_t *launches);
 int agx_timing_reset(agx_ctx *ctx);
 int agx_sync(agx_ctx *ctx);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@ maps, and that both shared libraries export every symbol the header declares.
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -38,6 +39,32 @@ def test_product_library_exports_every_symbol():
     lib7 = ctypes.CDLL(aither_amd.RANS_LIB_PATH)
     for name in abi.SYMBOLS:
         assert hasattr(lib7, "agx_" + name), name
+
+
+def test_product_libraries_export_only_the_c_abi():
+    """The 5- and 7-equation libraries are one source tree compiled for two state layouts:
+    kernel handles, device stubs and C++ internals of one must never resolve into the
+    other, so nothing but agx_* may appear in either dynamic symbol table --
+    and both can then be loaded RTLD_GLOBAL into one process."""
+    import subprocess
+    import aither_amd
+    for path in (aither_amd.LIB_PATH, aither_amd.RANS_LIB_PATH):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+        assert names and all(n.startswith("agx_") for n in names), \
+            [n for n in names if not n.startswith("agx_")][:5]
+        assert {n[4:] for n in names} == set(abi.SYMBOLS)
+    # in a fresh interpreter (this one may hold torch's own copy of the HIP runtime, which
+    # must not be mixed with /opt/rocm's through the global scope)
+    code = ("import ctypes, sys\n"
+            "a = ctypes.CDLL(sys.argv[1], mode=ctypes.RTLD_GLOBAL)\n"
+            "b = ctypes.CDLL(sys.argv[2], mode=ctypes.RTLD_GLOBAL)\n"
+            "a.agx_version.restype = b.agx_version.restype = ctypes.c_char_p\n"
+            "assert b'gfx950' in a.agx_version() and b'gfx950' in b.agx_version()\n"
+            "print('both loaded')\n")
+    out = subprocess.check_output([sys.executable, "-c", code, aither_amd.LIB_PATH,
+                                   aither_amd.RANS_LIB_PATH], text=True)
+    assert "both loaded" in out
 
 
 def test_product_library_fails_loudly_without_gpu():
