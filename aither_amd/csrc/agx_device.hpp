@@ -213,67 +213,74 @@ __device__ __forceinline__ void lagrange_coeff(const double* w, int rr, int ii,
     coeffs[jj] = c * w[ii - rr + jj];
   }
 }
+// FaceReconWENO reconstruction.hpp:244-310 in divided-difference (Newton) form.
+//
+// The reference evaluates Shu's formula 2.20 (LagrangeCoeff, utility.cpp:449-483: triple
+// loops over products of stencil widths, nine coefficients for the three quadratic
+// sub-stencils and five for the quartic one) per face side.  The same polynomials written
+// on the divided differences of the cell averages need a handful of width sums and
+// reciprocals instead: with the five widths w0..w4 (w2: the cell next to the face, w3, w4
+// downwind), the face at the upper edge of cell 2, pair sums p_a = w_a + w_{a+1},
+//     H_a = (u_{a+1} - u_a) * 2 / p_a               (twice the first divided difference)
+//     E_m = H_{m+1} - H_m
+//     s0 = u2 + w2/2 H_1 + [w2 p_1 / (2 (w0+w1+w2))] E_0
+//     s1 = u2 + w2/2 H_2 - [w2 w3 / (2 (w1+w2+w3))] E_1
+//     s2 = u2 + w2/2 H_2 - [w2 w3 / (2 (w2+w3+w4))] E_2
+// (uniform widths: 1/3 u0 - 7/6 u1 + 11/6 u2 etc.), and the linear weights
+//     fullCoeffs[0] / coeffs0[0] = w3 (w3+w4) / ((w0+..+w3)(w0+..+w4))
+//     fullCoeffs[4] / coeffs2[2] = (w0+w1+w2)(w1+w2) / ((w0+..+w4)(w1+..+w4))
+// (1/10 and 3/10; the reference gives the SECOND one to stencil 1 and 1 - both to stencil 2,
+// reconstruction.hpp:281-283, kept).  H and E are also exactly what Derivative2nd
+// (utility.hpp:114-120) and Beta0/1/2 (reconstruction.hpp:186-240) are made of:
+//     deriv2nd_m = E_m * 4 / (p_m + p_{m+1}),   deriv1st = H_1 + w2/2 d2 | H_2 - w2/2 d2.
+// 84 + 56 per variable fp64 instructions per face side instead of 258 + 71, and a
+// width-only set of 16 doubles instead of 19 + the five widths (tools/weno_closed_form.py
+// checks the algebra against formula 2.20 on random widths).
 struct WenoCoeffs {  // everything that depends on cell widths only
-  double c0[3], c1[3], c2[3], lw0, lw1, lw2;
-  // reciprocals of the width-only denominators of Derivative2nd / Beta0-2:
-  // ih[a] = 1 / (0.5 (cw[a] + cw[a+1])), iq[m] = 1 / (0.25 (cw[m+2] + cw[m]) + 0.5 cw[m+1])
-  double ih[4], iq[3];
+  double ih[4];        // 2 / p_a
+  double iq[3];        // 4 / (p_m + p_{m+1})
+  double a2;           // w2 / 2
+  double k0, k1, k2;   // the bracketed factors of E_0, E_1, E_2 above
+  double lw0, lw1, lw2;
+  double dx2, c13;     // w2^2, 13/12 w2^2
 };
 __device__ __forceinline__ void weno_coeffs(const double* cw, WenoCoeffs& k) {
-  double cf[5];
-  lagrange_coeff<2>(cw, 2, 2, k.c0);
-  lagrange_coeff<2>(cw, 1, 2, k.c1);
-  lagrange_coeff<2>(cw, 0, 2, k.c2);
-  lagrange_coeff<4>(cw, 2, 2, cf);
-  k.lw0 = fast_div(cf[0], k.c0[0]);
-  k.lw1 = fast_div(cf[4], k.c2[2]);
+  const double p0 = cw[0] + cw[1], p1 = cw[1] + cw[2], p2 = cw[2] + cw[3], p3 = cw[3] + cw[4];
+  k.ih[0] = fast_rcp(0.5 * p0); k.ih[1] = fast_rcp(0.5 * p1);
+  k.ih[2] = fast_rcp(0.5 * p2); k.ih[3] = fast_rcp(0.5 * p3);
+  k.iq[0] = fast_rcp(0.25 * (p0 + p1));
+  k.iq[1] = fast_rcp(0.25 * (p1 + p2));
+  k.iq[2] = fast_rcp(0.25 * (p2 + p3));
+  const double s012 = p0 + cw[2], s123 = p1 + cw[3], s234 = p2 + cw[4];
+  k.a2 = 0.5 * cw[2];
+  const double a23 = k.a2 * cw[3];
+  k.k0 = k.a2 * p1 * fast_rcp(s012);
+  k.k1 = a23 * fast_rcp(s123);
+  k.k2 = a23 * fast_rcp(s234);
+  const double w4 = p0 + p2, w5 = w4 + cw[4];
+  k.lw0 = cw[3] * p3 * fast_rcp(w4 * w5);
+  k.lw1 = s012 * p1 * fast_rcp(w5 * (p1 + p3));
   k.lw2 = 1.0 - k.lw0 - k.lw1;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) k.ih[a] = fast_rcp(0.5 * (cw[a] + cw[a + 1]));
-#pragma unroll
-  for (int m = 0; m < 3; ++m)
-    k.iq[m] = fast_rcp(0.25 * (cw[m + 2] + cw[m]) + 0.5 * cw[m + 1]);
+  k.dx2 = cw[2] * cw[2];
+  k.c13 = (13.0 / 12.0) * k.dx2;
 }
-// Derivative2nd utility.hpp:114-120, BetaIntegral / Beta0/1/2
-// reconstruction.hpp:158-240
-// BetaIntegral reconstruction.hpp:158-183 evaluated between xl = -dx/2 and
-// xh = +dx/2 (the only limits Beta0/1/2 use): the terms odd in x cancel exactly
-// (xh^2 == xl^2 in floating point too), leaving
-//   dx^2 (d1^2 + 13/12 d2^2 dx^2)
-__device__ __forceinline__ double beta_int(double d1, double d2, double dx) {
-  const double dx2 = dx * dx;
-  return dx2 * (d1 * d1 + (13.0 / 12.0) * (d2 * d2) * dx2);
-}
-// ih21 = 1 / (0.5 (x2 + x1)), ih10 = 1 / (0.5 (x1 + x0)), iq = 1 / (0.25 (x2 + x0) + 0.5 x1)
-__device__ __forceinline__ double deriv2(double ih10, double ih21, double iq,
-                                         double y0, double y1, double y2) {
-  const double fwd = (y2 - y1) * ih21;
-  const double bck = (y1 - y0) * ih10;
-  return (fwd - bck) * iq;
-}
+// BetaIntegral reconstruction.hpp:158-183 between -dx/2 and +dx/2 (the only limits
+// Beta0/1/2 use): the terms odd in x cancel exactly, leaving dx^2 (d1^2 + 13/12 d2^2 dx^2)
 template <bool WENOZ>
-__device__ __forceinline__ double weno(const WenoCoeffs& k, const double* cw,
-                                       double u3, double u2, double u1,
-                                       double d1, double d2) {
-  const double s0 = k.c0[0] * u3 + k.c0[1] * u2 + k.c0[2] * u1;
-  const double s1 = k.c1[0] * u2 + k.c1[1] * u1 + k.c1[2] * d1;
-  const double s2 = k.c2[0] * u1 + k.c2[1] * d1 + k.c2[2] * d2;
-  double b0, b1, b2;
-  {
-    const double dd = deriv2(k.ih[0], k.ih[1], k.iq[0], u3, u2, u1);
-    const double df = (u1 - u2) * k.ih[1] + 0.5 * cw[2] * dd;
-    b0 = beta_int(df, dd, cw[2]);
-  }
-  {
-    const double dd = deriv2(k.ih[1], k.ih[2], k.iq[1], u2, u1, d1);
-    const double df = (d1 - u1) * k.ih[2] - 0.5 * cw[2] * dd;
-    b1 = beta_int(df, dd, cw[2]);
-  }
-  {
-    const double dd = deriv2(k.ih[2], k.ih[3], k.iq[2], u1, d1, d2);
-    const double df = (d1 - u1) * k.ih[2] - 0.5 * cw[2] * dd;
-    b2 = beta_int(df, dd, cw[2]);
-  }
+__device__ __forceinline__ double weno(const WenoCoeffs& k, double u0, double u1, double u2,
+                                       double u3, double u4) {
+  const double h0 = (u1 - u0) * k.ih[0], h1 = (u2 - u1) * k.ih[1];
+  const double h2 = (u3 - u2) * k.ih[2], h3 = (u4 - u3) * k.ih[3];
+  const double e0 = h1 - h0, e1 = h2 - h1, e2 = h3 - h2;
+  const double c2 = fma(k.a2, h2, u2);
+  const double s0 = fma(k.k0, e0, fma(k.a2, h1, u2));
+  const double s1 = fma(-k.k1, e1, c2);
+  const double s2 = fma(-k.k2, e2, c2);
+  const double dd0 = e0 * k.iq[0], dd1 = e1 * k.iq[1], dd2 = e2 * k.iq[2];
+  const double df0 = fma(k.a2, dd0, h1), df1 = fma(-k.a2, dd1, h2), df2 = fma(-k.a2, dd2, h2);
+  const double b0 = k.dx2 * fma(k.c13, dd0 * dd0, df0 * df0);
+  const double b1 = k.dx2 * fma(k.c13, dd1 * dd1, df1 * df1);
+  const double b2 = k.dx2 * fma(k.c13, dd2 * dd2, df2 * df2);
   double n0, n1, n2;
   if (WENOZ) {
     const double tau5 = fabs(b0 - b2);
@@ -283,13 +290,16 @@ __device__ __forceinline__ double weno(const WenoCoeffs& k, const double* cw,
     n1 = k.lw1 * (1.0 + q1 * q1);
     n2 = k.lw2 * (1.0 + q2 * q2);
   } else {
-    const double e0 = 1.0e-6 + b0, e1 = 1.0e-6 + b1, e2 = 1.0e-6 + b2;
-    n0 = fast_div(k.lw0, e0 * e0);
-    n1 = fast_div(k.lw1, e1 * e1);
-    n2 = fast_div(k.lw2, e2 * e2);
+    // lw_m / (eps + b_m)^2, all three scaled by the product of the squares: one
+    // reciprocal (of the sum) instead of four
+    const double g0 = 1.0e-6 + b0, g1 = 1.0e-6 + b1, g2 = 1.0e-6 + b2;
+    const double p12 = g1 * g2, p02 = g0 * g2, p01 = g0 * g1;
+    n0 = k.lw0 * (p12 * p12);
+    n1 = k.lw1 * (p02 * p02);
+    n2 = k.lw2 * (p01 * p01);
   }
   const double inv = fast_rcp(n0 + n1 + n2);
-  return (n0 * s0 + n1 * s1 + n2 * s2) * inv;
+  return fma(n0, s0, fma(n1, s1, n2 * s2)) * inv;
 }
 
 // ---- inviscid fluxes --------------------------------------------------------

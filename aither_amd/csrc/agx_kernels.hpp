@@ -197,9 +197,9 @@ __device__ __forceinline__ void face_states_1d(double kappa, const double (*st)[
     weno_coeffs(cwr, kr);
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) {
-      l[e] = weno<RECON == AGX_RECON_WENOZ>(kl, cwl, st[c - 3][e], st[c - 2][e],
+      l[e] = weno<RECON == AGX_RECON_WENOZ>(kl, st[c - 3][e], st[c - 2][e],
                                             st[c - 1][e], st[c][e], st[c + 1][e]);
-      r[e] = weno<RECON == AGX_RECON_WENOZ>(kr, cwr, st[c + 2][e], st[c + 1][e],
+      r[e] = weno<RECON == AGX_RECON_WENOZ>(kr, st[c + 2][e], st[c + 1][e],
                                             st[c][e], st[c - 1][e], st[c - 2][e]);
     }
   }
@@ -395,8 +395,8 @@ __device__ __forceinline__ void recon_face(const SlabDev& b, int d, long qc,
       double u[6];
 #pragma unroll
       for (int m = 0; m < 6; ++m) u[m] = p[qc + (m - 3) * s];
-      l[e] = weno<RECON == AGX_RECON_WENOZ>(kl, cwl, u[0], u[1], u[2], u[3], u[4]);
-      r[e] = weno<RECON == AGX_RECON_WENOZ>(kr, cwr, u[5], u[4], u[3], u[2], u[1]);
+      l[e] = weno<RECON == AGX_RECON_WENOZ>(kl, u[0], u[1], u[2], u[3], u[4]);
+      r[e] = weno<RECON == AGX_RECON_WENOZ>(kr, u[5], u[4], u[3], u[2], u[1]);
     }
   }
 }
@@ -629,9 +629,9 @@ __device__ __forceinline__ void recon_generic(Get get, GetW getw, double kappa,
       r[e] = muscl<LIM>(up, u0, u1, dPr, dMr, kappa);
     }
   } else {
-    // one side at a time: the width-only coefficient set of a side is 19
-    // doubles, and holding both sets across the variable loop is what drove
-    // this path into scratch
+    // one side at a time: the width-only coefficient set of a side is 16 doubles
+    // (agx_device.hpp: WenoCoeffs), and holding both sets across the variable loop
+    // costs more registers than the shared reciprocals save instructions
     {
       double cw[5];
 #pragma unroll
@@ -640,7 +640,7 @@ __device__ __forceinline__ void recon_generic(Get get, GetW getw, double kappa,
       weno_coeffs(cw, kc);
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e)
-        l[e] = weno<RECON == AGX_RECON_WENOZ>(kc, cw, get(e, -3), get(e, -2), get(e, -1),
+        l[e] = weno<RECON == AGX_RECON_WENOZ>(kc, get(e, -3), get(e, -2), get(e, -1),
                                               get(e, 0), get(e, 1));
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -652,7 +652,7 @@ __device__ __forceinline__ void recon_generic(Get get, GetW getw, double kappa,
       weno_coeffs(cw, kc);
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e)
-        r[e] = weno<RECON == AGX_RECON_WENOZ>(kc, cw, get(e, 2), get(e, 1), get(e, 0),
+        r[e] = weno<RECON == AGX_RECON_WENOZ>(kc, get(e, 2), get(e, 1), get(e, 0),
                                               get(e, -1), get(e, -2));
     }
   }
