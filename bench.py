@@ -168,34 +168,44 @@ REFERENCE_SURVEY = {
 
 
 def cpu_baseline(workload, budget_s=12.0):
-    """The CPU oracle (a from-scratch scalar port of the reference algorithm,
-    NOT the reference binary) on a bounded sample of the same workload."""
+    """The CPU oracle (a from-scratch port of the reference algorithm, NOT the reference
+    binary) on a bounded sample of the same workload: on ALL host cores of this box
+    (OpenMP over k-planes / hyperplane cells, oracle/oracle.c; core count stated) at
+    96^3, with the one-thread figure at 48^3 beside it."""
     lib = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(lib):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")],
                               stdout=subprocess.DEVNULL)
     ora = abi.Api(ctypes.CDLL(lib), "ora_")
-    n = 48
-    case = rank_local_chain_case(0, 1, n, workload)
-    nonlin = case.deck.nonlinear_iterations
-    s = Solver(ora, case)
-    s.store_time_n(0)
-    s.iterate(0, 0.5)                      # warm-up
-    its, t0 = 0, time.perf_counter()
-    # (the perturbed synthetic rans start is only followed for a few iterations)
-    max_its = 6 if workload == "rans4" else 1 << 30
-    while time.perf_counter() - t0 < budget_s and its < max_its:
-        if its % nonlin == 0:
-            s.store_time_n(its // nonlin)
-        s.iterate(its % nonlin, case.deck.cfl(0))
-        its += 1
-    dt = time.perf_counter() - t0
-    s.close()
-    out = dict(value=case.total_cells * its / dt / 1e6, unit="Mcell-updates/s", cores=1,
-               kind="port",
-               sample=f"{its} iterations of the same scheme on {case.total_cells} cells "
-                      f"(size parameter {n}; {dt:.1f} s, oracle/liboracle.so, gcc -O2, 1 thread)")
+    gomp = ctypes.CDLL("libgomp.so.1")
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+
+    def timed(n, threads, budget):
+        gomp.omp_set_num_threads(threads)
+        case = rank_local_chain_case(0, 1, n, workload)
+        nonlin = case.deck.nonlinear_iterations
+        s = Solver(ora, case)
+        s.store_time_n(0)
+        s.iterate(0, 0.5)                      # warm-up
+        its, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget and its < 1 << 30:
+            if its % nonlin == 0:
+                s.store_time_n(its // nonlin)
+            s.iterate(its % nonlin, case.deck.cfl(0))
+            its += 1
+        dt = time.perf_counter() - t0
+        s.close()
+        return dict(value=case.total_cells * its / dt / 1e6, unit="Mcell-updates/s",
+                    cores=threads,
+                    sample=f"{its} iterations of the same scheme on {case.total_cells} cells "
+                           f"(size parameter {n}; {dt:.1f} s, oracle/liboracle.so, gcc -O2 "
+                           f"-fopenmp, {threads} thread{'s' if threads > 1 else ''})")
+
+    multi = timed(96, cores, budget_s)
+    single = timed(48, 1, 0.5 * budget_s)
+    gomp.omp_set_num_threads(cores)
+    out = dict(multi, kind="port", single_thread=single)
     if workload in REFERENCE_SURVEY:
         out["reference_survey"] = REFERENCE_SURVEY[workload]
     return out

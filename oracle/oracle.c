@@ -1523,9 +1523,16 @@ static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
   const int nn[3] = {b->ni, b->nj, b->nk};
   const int o[3] = {d == 0, d == 1, d == 2};
   const int implicit = c->cfg.time_integration >= AGX_TIME_IMPLICIT_EULER;
-  for (int k = 0; k < b->nk + o[2]; ++k)
-    for (int j = 0; j < b->nj + o[1]; ++j)
+  /* threads (cpu_baseline on all host cores) take whole k-planes -- j-rows for the
+   * k-faces --, so the two cells a face adds to belong to one thread and every cell
+   * receives its contributions in the serial order: the result does not depend on
+   * the number of threads */
+  const int n_outer = d == 2 ? b->nj : b->nk, n_inner = d == 2 ? b->nk + 1 : b->nj + o[1];
+#pragma omp parallel for schedule(static)
+  for (int outer = 0; outer < n_outer; ++outer)
+    for (int inner = 0; inner < n_inner; ++inner)
       for (int i = 0; i < b->ni + o[0]; ++i) {
+        const int k = d == 2 ? inner : outer, j = d == 2 ? outer : inner;
         double fl[NEQM], fr[NEQM], flux[NEQM];
         face_states(c, b, d, i, j, k, fl, fr);
         const double *area = b->fa[d] + 4 * FI(b, d, i, j, k);
@@ -1584,6 +1591,7 @@ static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
 
 /* procBlock::UpdateAuxillaryVariables procBlock.cpp:6171-6189 */
 static void update_aux(ora_ctx *c, blk_t *b) {
+#pragma omp parallel for schedule(static)
   for (int k = -b->ng; k < b->nk + b->ng; ++k)
     for (int j = -b->ng; j < b->nj + b->ng; ++j)
       for (int i = -b->ng; i < b->ni + b->ng; ++i) {
@@ -1918,9 +1926,16 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
   const int implicit = c->cfg.time_integration >= AGX_TIME_IMPLICIT_EULER;
   const double viscCoeff = c->cfg.viscous_cfl_coeff;
   const double sixth = 1.0 / 6.0;
-  for (int k = 0; k < b->nk + o[2]; ++k)
-    for (int j = 0; j < b->nj + o[1]; ++j)
+  /* threads (cpu_baseline on all host cores) take whole k-planes -- j-rows for the
+   * k-faces --, so the two cells a face adds to belong to one thread and every cell
+   * receives its contributions in the serial order: the result does not depend on
+   * the number of threads */
+  const int n_outer = d == 2 ? b->nj : b->nk, n_inner = d == 2 ? b->nk + 1 : b->nj + o[1];
+#pragma omp parallel for schedule(static)
+  for (int outer = 0; outer < n_outer; ++outer)
+    for (int inner = 0; inner < n_inner; ++inner)
       for (int i = 0; i < b->ni + o[0]; ++i) {
+        const int k = d == 2 ? inner : outer, j = d == 2 ? outer : inner;
         const int rans = NEQ > NF;
         double velGrad[9], tGrad[3], kGrad[3] = {0, 0, 0}, wGrad[3] = {0, 0, 0};
         calc_grads(b, d, i, j, k, velGrad, tGrad, rans ? kGrad : NULL, rans ? wGrad : NULL);
@@ -2075,6 +2090,7 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
 static void calc_src_terms(ora_ctx *c, blk_t *b) {
   const int implicit = c->cfg.time_integration >= AGX_TIME_IMPLICIT_EULER;
   const double invScaling = 1.0 / c->scaling;
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
@@ -2206,7 +2222,15 @@ static int calc_dt(ora_ctx *c, blk_t *b, double cfl) {
 static void update_block(ora_ctx *c, blk_t *b, int rr, double *l2,
                          agx_linf *linf) {
   const double alpha[4] = {0.25, 1.0 / 3.0, 0.5, 1.0};
-  for (int k = 0; k < b->nk; ++k)
+  /* per k-plane partial norms, folded in plane order below (the same result for any
+   * number of threads) */
+  double *pl2 = (double *)calloc((size_t)b->nk * NEQM, sizeof(double));
+  agx_linf *plinf = (agx_linf *)malloc((size_t)b->nk * sizeof(agx_linf));
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < b->nk; ++k) {
+    double *l2k = pl2 + (size_t)k * NEQM;
+    agx_linf *lk = plinf + k;
+    lk->linf = -1.7976931348623157e308; lk->block = lk->i = lk->j = lk->k = lk->eqn = 0;
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
@@ -2227,17 +2251,29 @@ static void update_block(ora_ctx *c, blk_t *b, int rr, double *l2,
           update_prim_with_cons(c, s, b->x + NEQ * q, ns);
         }
         memcpy(s, ns, sizeof(double) * NEQ);
-        for (int e = 0; e < NEQ; ++e) l2[e] += r[e] * r[e];
+        for (int e = 0; e < NEQ; ++e) l2k[e] += r[e] * r[e];
         for (int e = 0; e < NEQ; ++e) {
-          if (r[e] > linf->linf) {
-            linf->linf = r[e];
-            linf->block = b->parent;
-            linf->i = i; linf->j = j; linf->k = k;
-            linf->eqn = e + 1;
+          if (r[e] > lk->linf) {
+            lk->linf = r[e];
+            lk->block = b->parent;
+            lk->i = i; lk->j = j; lk->k = k;
+            lk->eqn = e + 1;
           }
         }
       }
+  }
+  for (int k = 0; k < b->nk; ++k) {
+    for (int e = 0; e < NEQ; ++e) l2[e] += pl2[(size_t)k * NEQM + e];
+    if (plinf[k].linf > linf->linf) {
+      const int32_t pad = linf->pad_;
+      *linf = plinf[k];
+      linf->pad_ = pad;
+    }
+  }
+  free(pl2);
+  free(plinf);
 }
+
 
 /* ------------------------------------------------------------------------ */
 /* implicit                                                                  */
@@ -2398,6 +2434,8 @@ static void apply_ainv(const ora_ctx *c, const blk_t *b, long p, const double *v
   }
 }
 static int implicit_begin(ora_ctx *c, blk_t *b) {
+  int singular = 0;
+#pragma omp parallel for schedule(static) reduction(|:singular)
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
@@ -2424,16 +2462,18 @@ static int implicit_begin(ora_ctx *c, blk_t *b) {
             m[NF * e + e] += diagVolTime;
           }
           memcpy(mi, m, sizeof(double) * NJ);
-          if (matrix_inverse(mi, NF)) return 1;
+          if (matrix_inverse(mi, NF)) { singular |= 1; continue; }
           for (int e = 0; e < NEQ - NF; ++e) {
             b->am_t[2 * p + e] *= c->cfg.matrix_relaxation;
             b->am_t[2 * p + e] += diagVolTime;
-            if (b->am_t[2 * p + e] == 0.0) return fail("Singular matrix in Gauss-Jordan elimination!");
+            if (b->am_t[2 * p + e] == 0.0) { singular |= 1; continue; }
             b->aminv_t[2 * p + e] = 1.0 / b->am_t[2 * p + e];
           }
         }
       }
+  if (singular) return fail("Singular matrix in Gauss-Jordan elimination!");
   if (requires_init(c)) {
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < b->nk; ++k)
       for (int j = 0; j < b->nj; ++j)
         for (int i = 0; i < b->ni; ++i) {
@@ -2453,6 +2493,7 @@ static int implicit_begin(ora_ctx *c, blk_t *b) {
 static void lusgs_forward(ora_ctx *c, blk_t *b, int sweep) {
   const int nplanes = b->ni + b->nj + b->nk - 2;
   for (int pp = 0; pp < nplanes; ++pp)
+#pragma omp parallel for schedule(static)   /* the cells of a hyperplane are independent */
     for (int k = 0; k < b->nk; ++k)
       for (int j = 0; j < b->nj; ++j) {
         const int i = pp - j - k;
@@ -2474,6 +2515,7 @@ static void lusgs_forward(ora_ctx *c, blk_t *b, int sweep) {
 static void lusgs_backward(ora_ctx *c, blk_t *b, int sweep) {
   const int nplanes = b->ni + b->nj + b->nk - 2;
   for (int pp = nplanes - 1; pp >= 0; --pp)
+#pragma omp parallel for schedule(static)
     for (int k = b->nk - 1; k >= 0; --k)
       for (int j = b->nj - 1; j >= 0; --j) {
         const int i = pp - j - k;
@@ -2497,6 +2539,7 @@ static void lusgs_backward(ora_ctx *c, blk_t *b, int sweep) {
 /* dplur::DPLUR linearSolver.cpp:473-507 */
 static void dplur_sweep(ora_ctx *c, blk_t *b) {
   memcpy(b->xold, b->x, sizeof(double) * NEQ * b->ncell_g);
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
@@ -2514,6 +2557,8 @@ static void dplur_sweep(ora_ctx *c, blk_t *b) {
 /* linearSolver::AXmB :58-90 and Residual :92-109, squared and summed as in
  * mgSolution::CycleAtLevel mgSolution.cpp:198-206 */
 static void matrix_residual(ora_ctx *c, blk_t *b, double *sumsq, long *size) {
+  double *part = (double *)calloc((size_t)b->nk, sizeof(double));
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
@@ -2534,9 +2579,11 @@ static void matrix_residual(ora_ctx *c, blk_t *b, double *sumsq, long *size) {
         for (int e = 0; e < NEQ; ++e) {
           const double axmb = ax[e] - off[e] - rb[e];
           const double r = 0.0 - axmb;
-          *sumsq += r * r;
+          part[k] += r * r;
         }
       }
+  for (int k = 0; k < b->nk; ++k) *sumsq += part[k];   /* folded in plane order */
+  free(part);
   *size += NEQ * b->ncell_g;
 }
 
