@@ -85,11 +85,12 @@ def make_deck(**kw):
     wall = {}
     if kw.get("wall_treatment") is not None:
         wall = dict(wallTreatment=kw["wall_treatment"])
+    vel = list(kw.get("velocity", [50.0, 20.0, 10.0]))     # free stream, m/s
     d.ics = [State("icState", dict(tag=-1, pressure=101325.0, density=1.225,
-                                   velocity=[50.0, 20.0, 10.0], **turb))]
+                                   velocity=vel, **turb))]
     d.bc_states = [
         State("characteristic", dict(tag=1, pressure=101325.0, density=1.225,
-                                     velocity=[50.0, 20.0, 10.0], **turb)),
+                                     velocity=vel, **turb)),
         State("viscousWall", dict(tag=2, **wall)),
         State("pressureOutlet", dict(tag=3, pressure=101325.0)),
         State("viscousWall", dict(tag=4, temperature=300.0,
