@@ -47,8 +47,8 @@ struct Block {
   std::vector<int> dstart;    // host copy (halo index maps)
   // hyperplane-per-launch sweeps captured as graphs: [forward][both triangles][un_is_u]
   hipGraphExec_t sweep_graph[2][2][2] = {};
-  int* kp_mem = nullptr;      // k_lusgs_kp: progress flag per k-plane | ticket
-  int kp_epoch = 0;
+  int* kp_mem = nullptr;      // k_lusgs_kp: ticket counter
+  unsigned kp_epoch = 0;      // writer launches of the D2 x so far (its low bits tag the values)
   // D2 index of padded cell (i, j, k), host side
   long d2idx(int i, int j, int k) const {
     const int ie = i + d.ng, je = j + d.ng, de = ie + je;
@@ -566,22 +566,16 @@ bool use_d2(const agx_ctx* c) {
 template <bool FWD, bool FULL, bool CONN, int CH>
 int lusgs_kp_launch(agx_ctx* c, Block& blk) {
   const BlockDev& b = blk.d;
-  // one progress counter per k-plane, each on a cache line of its own, + the ticket
-  const size_t kp_ints = ((size_t)b.nk + 1) * KP_FLAG_STRIDE;
-  if (!blk.kp_mem) {
-    HIPCHK(hipMalloc((void**)&blk.kp_mem, sizeof(int) * kp_ints));
-    HIPCHK(hipMemsetAsync(blk.kp_mem, 0, sizeof(int) * kp_ints, c->stream));
-    blk.kp_epoch = 0;
-  }
-  if (blk.kp_epoch >= 30000) {   // flags hold epoch << 16 | steps: restart before it wraps
-    HIPCHK(hipMemsetAsync(blk.kp_mem, 0, sizeof(int) * kp_ints, c->stream));
-    blk.kp_epoch = 0;
+  if (!blk.kp_mem) {                      // the ticket counter
+    HIPCHK(hipMalloc((void**)&blk.kp_mem, sizeof(int) * 32));
+    HIPCHK(hipMemsetAsync(blk.kp_mem, 0, sizeof(int) * 32, c->stream));
   }
   KpArgs kp;
-  kp.flags = blk.kp_mem;
-  kp.ticket = blk.kp_mem + (size_t)b.nk * KP_FLAG_STRIDE;
+  kp.ticket = blk.kp_mem;
   kp.err = c->err_dev;
-  kp.epoch = ++blk.kp_epoch;
+  // the launch's tag of the values it stores (agx_lusgs_kernels.hpp: KpArgs); every
+  // writer of x advances the block's epoch
+  kp.tag = (unsigned)(++blk.kp_epoch) & 3u;
   kp.spin_limit = c->spin_limit;
   kp.trace = nullptr;
 #ifdef AGX_KP_TRACE
@@ -1515,7 +1509,8 @@ static int field_info(Block& b, int field, double* const** p, int* ncomp, int* g
 static int d2_x_copy(agx_ctx* c, Block& b, int to_d2) {
 #if AGX_FAST
   const long n = (long)b.d.d2.Pi * b.d.d2.Pj * (b.d.nk + 2 * b.d.ng);
-  hipLaunchKernelGGL(k_d2_x_copy, dim3((n + 255) / 256), dim3(256), 0, c->stream, b.d, to_d2);
+  hipLaunchKernelGGL(k_d2_x_copy, dim3((n + 255) / 256), dim3(256), 0, c->stream, b.d, to_d2,
+                     to_d2 ? (unsigned)(++b.kp_epoch) & 3u : 0u);
   HIPCHK(hipGetLastError());
 #endif
   return 0;
@@ -1657,14 +1652,14 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
           continue;
         }
 #if AGX_FAST
-        // 62 x 6 owned cells per workgroup, k cut into chunks so that >= ~4
-        // workgroups per CU exist (the first pass of a chunk only primes the k-face)
+        // 62 x 6 owned cells per workgroup and k-step; persistent workgroups, one per CU
+        // (the kernel's LDS windows fill a CU), each marching an equal share of the
+        // (column tile, k) steps
         const int gx = (vb.ni + VT_OI - 1) / VT_OI, gy = (vb.nj + VT_OJ - 1) / VT_OJ;
-        int nz = std::max(1, std::min(vb.nk / 16, (int)std::lround(4.0 * c->num_cu / (gx * gy))));
-        const int kchunk = (vb.nk + nz - 1) / nz;
-        nz = (vb.nk + kchunk - 1) / kchunk;
-        hipLaunchKernelGGL(k_visc_tile, dim3(gx, gy, nz), dim3(VT_L, VT_R), 0, c->stream,
-                           make_slab(vb), c->gas, c->sp, cfl, kchunk);
+        const long steps = (long)gx * gy * vb.nk;
+        const int nwg = (int)std::min<long>(c->num_cu, std::max<long>(1, steps / 8));
+        hipLaunchKernelGGL(k_visc_tile, dim3(nwg), dim3(VT_L, VT_R), 0, c->stream,
+                           make_slab(vb), c->gas, c->sp, cfl, gx, gy);
 #endif
       }
 #endif  // AGX_NEQ == 7
@@ -1705,8 +1700,10 @@ int agx_phase_implicit_begin(agx_ctx* c) {
       const dim3 grid((b.d2.Pi + TT - 1) / TT, (b.d2.Pj + TT - 1) / TT, b.nk + 2 * b.ng);
       bool conn = false;
       for (int q = 0; q < 6; ++q) conn = conn || b.side_conn[q] != 0;
+      const int write_x = (c->sp.requires_init || conn) ? 1 : 0;
+      // (a launch that writes x is a writer launch: it tags the values and advances the epoch)
       hipLaunchKernelGGL(k_lusgs_prepare, grid, dim3(256), 0, c->stream, b, c->gas, c->sp,
-                         (c->sp.requires_init || conn) ? 1 : 0);
+                         write_x, write_x ? (unsigned)(++blk.kp_epoch) & 3u : 0u);
       continue;
     }
 #endif

@@ -781,7 +781,10 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
       // MUSCL and below: requested first, a whole step ahead of its use.  WENO: the
       // k- and i-face with their coefficient sets leave no room for eight more live
       // values (256 VGPRs + scratch), so there it is requested after the i-face.
-      constexpr bool LATE = H >= 3;
+#ifndef AGX_WENO_LATE
+#define AGX_WENO_LATE 1
+#endif
+      constexpr bool LATE = AGX_WENO_LATE && H >= 3;
       if (!LATE) prefetch();
       // InvCellSpectralRadius spectralRadius.hpp:44-64, one direction per block
       const double* sc = W[H - 1];

@@ -28,6 +28,14 @@ __device__ __forceinline__ void tile_table(unsigned short* s_tab) {
   }
 }
 
+// tag of a writer launch in the two low mantissa bits of an x value (see KpArgs)
+__device__ __forceinline__ double kp_tagged(double v, unsigned tag) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return __longlong_as_double((long long)((u & ~3ull) | tag));
+}
+__device__ __forceinline__ bool kp_has_tag(double v, unsigned tag) {
+  return ((unsigned)__double_as_longlong(v) & 3u) == tag;
+}
 // viscous factor of a cell: visc_max_term * visc_term of ViscFaceSpectralRadius
 // (spectralRadius.hpp:94-160) with the laminar viscosity of
 // UpdateAuxillaryVariables (procBlock.cpp:6171); ghost corners may hold zeros
@@ -67,7 +75,7 @@ __global__ void __launch_bounds__(256) k_d2_geo(BlockDev b) {
   }
 }
 // x between the SoA planes and the D2 array (field download / upload only)
-__global__ void __launch_bounds__(256) k_d2_x_copy(BlockDev b, int to_d2) {
+__global__ void __launch_bounds__(256) k_d2_x_copy(BlockDev b, int to_d2, unsigned tag) {
   const D2Dev& z = b.d2;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)z.Pi * z.Pj * (b.nk + 2 * b.ng);
@@ -79,7 +87,7 @@ __global__ void __launch_bounds__(256) k_d2_x_copy(BlockDev b, int to_d2) {
 #pragma unroll
   for (int e = 0; e < AGX_NEQ; ++e) {
     double* xp = reinterpret_cast<double*>(z.pa(PA_X + (e >> 1))) + 2 * p + (e & 1);
-    if (to_d2) *xp = b.x[e][q];
+    if (to_d2) *xp = kp_tagged(b.x[e][q], tag);   // every writer of x tags it (KpArgs)
     else b.x[e][q] = *xp;
   }
 }
@@ -94,7 +102,7 @@ __global__ void __launch_bounds__(256) k_d2_x_copy(BlockDev b, int to_d2) {
 // without connection surfaces no ghost x is ever a neighbour) -- skip 48 B/cell.
 // Grid: (Pi / 32, Pj / 32, Pk) tiles of the padded box, 256 threads.
 __global__ void __launch_bounds__(256)
-k_lusgs_prepare(BlockDev b, GasDev g, SolverDev sp, int write_x) {
+k_lusgs_prepare(BlockDev b, GasDev g, SolverDev sp, int write_x, unsigned tag) {
   __shared__ double sv[6][TT][TRS];
   __shared__ unsigned short s_tab[TT * TT];
   const D2Dev& z = b.d2;
@@ -189,9 +197,12 @@ k_lusgs_prepare(BlockDev b, GasDev g, SolverDev sp, int write_x) {
   for (int m = 0; m < 4; ++m) {
     if (pos[m] >= 0) {
       if (write_x) {
-        z.pa(PA_X + 0)[pos[m]] = make_double2(sv[0][tlj[m]][tli[m]], sv[1][tlj[m]][tli[m]]);
-        z.pa(PA_X + 1)[pos[m]] = make_double2(sv[2][tlj[m]][tli[m]], sv[3][tlj[m]][tli[m]]);
-        z.pa(PA_X + 2)[pos[m]] = make_double2(sv[4][tlj[m]][tli[m]], ai2[m]);
+        // (every writer of x tags it: KpArgs)
+        z.pa(PA_X + 0)[pos[m]] = make_double2(kp_tagged(sv[0][tlj[m]][tli[m]], tag),
+                                              kp_tagged(sv[1][tlj[m]][tli[m]], tag));
+        z.pa(PA_X + 1)[pos[m]] = make_double2(kp_tagged(sv[2][tlj[m]][tli[m]], tag),
+                                              kp_tagged(sv[3][tlj[m]][tli[m]], tag));
+        z.pa(PA_X + 2)[pos[m]] = make_double2(kp_tagged(sv[4][tlj[m]][tli[m]], tag), ai2[m]);
       }
       if (sp.viscous) z.vf()[pos[m]] = sv[5][tlj[m]][tli[m]];
     }
@@ -270,11 +281,21 @@ __device__ __forceinline__ void kp_term_mem(const Z& z, const G& g, bool viscous
   kp_term(r, f.n, f.a, f.ad, viscous, lower, acc);
 }
 
+// Hand-off between the planes: DATA-TAGGED values, no flag.  Every x a sweep launch stores
+// carries the launch's tag in the two low mantissa bits of each double (<= 3 ulp, 7e-16
+// relative: five orders inside the parity budget; the tagged value is also the one handed
+// to the in-plane successors, so every consumer sees the same number).  The plane above
+// polls the doubles it needs themselves (sc1 loads) and goes on the moment they carry this
+// launch's tag -- what was there before carries the tag of an earlier writer launch
+// (prepare, the previous half sweep, an upload), all of which tag what they write and
+// advance the block's epoch.  Against flag + payload (store, drain, barrier, flag store,
+// poll, barrier, load) this takes the store acknowledgement, the flag's own trip and one
+// barrier out of every plane-to-plane hop.
 struct KpArgs {
-  int* flags;       // per k-plane: epoch << 16 | diagonals visible
   int* ticket;      // next k-plane to hand out
   int* err;
-  int epoch, spin_limit;
+  int spin_limit;
+  unsigned tag;     // epoch & 3 of this launch
   long long* trace;  // -DAGX_KP_TRACE builds: 6 timestamps per step of the middle plane
 };
 #ifdef AGX_KP_TRACE
@@ -297,22 +318,11 @@ struct KpCell {   // everything of one cell that does not depend on this launch
 // block has interblock / periodic surfaces, i.e. ghost cells can be neighbours.
 // The common case (one sweep, physical boundaries only) compiles without either
 // path: the step loop then has a single divergent branch (lane has a cell or not).
-// KP_DEFER: store the x of a diagonal at the top of the NEXT step (its drain is then
-// free, but the planes follow each other three steps apart instead of two)
-#ifndef KP_DEFER
-#define KP_DEFER 0
-#endif
-// KP_QX_AHEAD: request the k-neighbour's x one step before it is used (costs one
-// more step of distance between the planes)
-#ifndef KP_QX_AHEAD
-#define KP_QX_AHEAD 0
-#endif
 #ifndef KP_SLEEP
 #define KP_SLEEP 2
 #endif
-constexpr int KP_FLAG_STRIDE = 32;   // ints: one 128-byte line per progress counter
 template <bool FWD, bool FULL, bool CONN, int CH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 1)
 k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
   extern __shared__ double kp_lds[];          // [2][KP_NV][nsl]
   __shared__ int s_kt, s_ok;
@@ -320,27 +330,11 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
   const int tid = threadIdx.x;
   const int ng = b.ng;
   const int nsteps = b.ni + b.nj - 1;
-  const int ebase = kp.epoch << 16;
   const bool visc = viscous != 0;
   if (tid == 0) s_ok = 1;
   // records of cells that do not exist are read (and weighted with a zero face
   // area): keep every slot finite from the start
   for (int n = tid; n < 2 * KP_NV * nsl; n += 256) kp_lds[n] = 0.0;
-  auto wait_for = [&](int kq, int steps) {    // thread 0 only
-    const int need = ebase + steps;
-    int spins = 0;
-    while (__hip_atomic_load(kp.flags + kq * KP_FLAG_STRIDE, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(KP_SLEEP);
-      if (++spins > kp.spin_limit ||
-          __hip_atomic_load(kp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        s_ok = 0;
-        __hip_atomic_store(kp.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  };
   for (;;) {
     __syncthreads();
     if (tid == 0) s_kt = atomicAdd(kp.ticket, 1);
@@ -372,9 +366,12 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
 #pragma unroll
       for (int m = 0; m < CH; ++m) {
         KpCell& c = cc[m];
-        const int n = tid + 256 * m;
-        c.act = n < cnt;
-        if (!c.act) continue;
+        // a lane without a cell loads the diagonal's first cell (and ignores it): no
+        // branch around the loads -- at a join of paths with and without loads in
+        // flight the compiler's wait for anything older turns into a wait for everything
+        const int nraw = tid + 256 * m;
+        c.act = nraw < cnt;
+        const int n = c.act ? nraw : 0;
         c.j = jmin + n;
         c.i = d - c.j;
         c.pos = p0 + n;
@@ -422,83 +419,68 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
         c.use = use;            // bits 3, 4: in-plane neighbour q is a ghost cell
       }
     };
-    // Software pipeline of one step (everything asynchronous is a step old when it
-    // is waited for): at the top of step t the x of diagonal t-1 is stored
-    // (write-through) and the data of step t+1 is requested -- own cell from this
-    // plane, x of the k-neighbour from plane kq; the arithmetic of step t follows;
-    // the single s_waitcnt + barrier at the end therefore finds the stores of
-    // diagonal t-1 and the loads for t+1 (almost) complete, and thread 0 publishes
-    // "t diagonals visible".  Plane kq must be two diagonals further when its x
-    // is requested, so the planes follow each other three steps apart.
-    if (tid == 0 && has_pre) wait_for(kq, 1);
-    __syncthreads();
-    if (!s_ok) return;
+    // One step = one diagonal.  At its top the x of the k-neighbours (plane kq, same
+    // positions) and the data of step t+1 are requested; the two in-plane terms (records
+    // of the previous diagonal, LDS) are formed meanwhile; then the k-neighbour's values
+    // are checked for this launch's tag and asked for again until they carry it (see
+    // KpArgs); the k-term, x = ..., the tagged stores and the record for the next
+    // diagonal follow.  ONE barrier per step (the LDS records); nothing waits for a store.
     KpCell cur[CH], nxt[CH];
-    double2 qx[CH][3], qxn[CH][3], xst[CH][3];
-    unsigned pst[CH];            // byte offset of the cell inside its k-plane; ~0u: none
-    auto load_qx = [&](const KpCell* cc, double2 (*q)[3]) {
-      // agent-scope loads: the producer (another CU) stored these write-through
+    double qx[CH][AGX_NEQ];
+    // sc1 loads: the producer (another CU) stored these write-through
+    auto qx_request = [&]() {
 #pragma unroll
       for (int m = 0; m < CH; ++m) {
 #pragma unroll
-        for (int h = 0; h < 3; ++h) {
+        for (int e = 0; e < AGX_NEQ; ++e) {       // (lanes without a cell: see fetch)
           const double* p = reinterpret_cast<const double*>(
-              z.pab(PA_X + h) + qbase * 16 + (unsigned)cc[m].pos * 16u);
-          if (cc[m].act) {
-            q[m][h].x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (h < 2)
-              q[m][h].y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+              z.pab(PA_X + (e >> 1)) + qbase * 16 + (unsigned)cur[m].pos * 16u) + (e & 1);
+          qx[m][e] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     };
-#pragma unroll
-    for (int m = 0; m < CH; ++m) { pst[m] = ~0u; cur[m].act = false; }
-    int jmin_prev = 0;
-    // t = -1 only requests the data of step 0 (the register set of the running
-    // step is then only ever written by copies, never by loads in flight)
-    auto store_x = [&]() {
-      // x of a finished diagonal: to the next plane and to everybody after the launch
+    // (branch-free: one mask of all the low words against the tag)
+    auto qx_landed = [&]() {
+      unsigned bad = 0;
 #pragma unroll
       for (int m = 0; m < CH; ++m) {
-        if (pst[m] != ~0u) {
 #pragma unroll
-          for (int h = 0; h < 3; ++h) {
-            // one 16-byte write-through (sc1) store per pair: what an agent-scope
-            // atomic store lowers to, at twice the width HIP's atomics offer
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            const char* base = z.pab(PA_X + h) + kbase * 16;
-            const v2d val = {xst[m][h].x, xst[m][h].y};
-            // (s_nop 4: the base may have been written by a v_readlane just before --
-            // VALU-writes-SGPR -> VMEM needs 5 wait states, and the compiler's hazard
-            // recogniser does not look inside inline asm)
-            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1"
-                         :: "v"(pst[m]), "v"(val), "s"(base) : "memory");
-          }
-        }
-        pst[m] = ~0u;
+        for (int e = 0; e < AGX_NEQ; ++e)
+          bad |= cur[m].act ? ((unsigned)__double_as_longlong(qx[m][e]) ^ kp.tag) : 0u;
       }
+      return (bad & 3u) == 0u;
     };
-    for (int t = -1; t <= nsteps; ++t) {
+#pragma unroll
+    for (int m = 0; m < CH; ++m) {
+      cur[m].act = false;
+#pragma unroll
+      for (int e = 0; e < AGX_NEQ; ++e) qx[m][e] = 0.0;
+    }
+    int jmin_prev = 0;
+    // the data of step 0, complete before the loop: every path into the step then has
+    // nothing of the running register set in flight (a load the compiler believes pending
+    // at a join is waited for together with everything older -- the stores included)
+    fetch(0, cur);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int t = 0; t < nsteps; ++t) {
       KP_STAMP(0);
-      if (KP_DEFER) store_x();
-      if (!KP_QX_AHEAD && t >= 0 && t < nsteps) load_qx(cur, qx);
-      if (t + 1 < nsteps) {
-        fetch(t + 1, nxt);
-        if (KP_QX_AHEAD) load_qx(nxt, qxn);
-      }
+      if (k_any) qx_request();
+      fetch(min(t + 1, nsteps - 1), nxt);       // (unconditional: see fetch)
       KP_STAMP(1);
-      if (t >= 0 && t < nsteps) {
-      int d, jmin, cnt, p0, pn;
+      {
+        int d, jmin, cnt, p0, pn;
       step_geom(t, d, jmin, cnt, p0, pn);
       double* lw = kp_lds + (size_t)(t & 1) * KP_NV * nsl;          // this step's records
       const double* lr = kp_lds + (size_t)((t & 1) ^ 1) * KP_NV * nsl;  // previous diagonal
+      double accs[CH][AGX_NEQ];
 #pragma unroll
       for (int m = 0; m < CH; ++m) {
         const KpCell& c = cur[m];
-        if (!c.act) continue;
-        const long own = kbase + c.pos;
-        double acc[AGX_NEQ] = {0, 0, 0, 0, 0};
+        double* acc = accs[m];
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) acc[e] = 0.0;
+        // (lanes without a cell run along on the diagonal's first cell and store nothing:
+        // no branch around loads or stores, see fetch)
         // in-plane neighbours: slot of cell j' in the previous diagonal's records
         // is j' - jmin_prev + 1 (clamped: a neighbour outside the block has a zero
         // face area and any finite record will do)
@@ -522,12 +504,42 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
             kp_term(r, c.f[q].n, on ? c.f[q].a : 0.0, on ? c.f[q].ad : 0.0, true, FWD, acc);
           }
         }
+      }
+      KP_STAMP(2);
+      if (has_pre) {
+        // the k-neighbours' x of THIS launch (wave by wave: no barrier, no flag)
+        int spins = 0;
+        while (!__all(qx_landed())) {
+          __builtin_amdgcn_s_sleep(KP_SLEEP);
+          if (++spins > kp.spin_limit ||
+              ((spins & 63) == 0 &&
+               __hip_atomic_load(kp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            s_ok = 0;
+            __hip_atomic_store(kp.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          qx_request();
+          // (waited for here, inside the loop: a request left pending at the loop's exit
+          // makes the compiler's scoreboard wait for it -- and for everything older, the
+          // prefetch included -- wherever its registers are written next)
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+      }
+      KP_STAMP(3);
+      // the prefetch of the next diagonal, requested at the top of the step together with
+      // the k-neighbours' x that has just been seen: it has landed or is about to.  Waited
+      // for HERE, before this step's stores are issued (see the stores)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+      for (int m = 0; m < CH; ++m) {
+        const KpCell& c = cur[m];
+        double* acc = accs[m];
+        const long own = kbase + c.pos;
         // the k-neighbour last: its x was requested at the top of this step
         if (k_any) {
           const double qs5[AGX_NEQ] = {c.qs[0].x, c.qs[0].y, c.qs[1].x, c.qs[1].y, c.qs[2].x};
-          const double qx5[AGX_NEQ] = {qx[m][0].x, qx[m][0].y, qx[m][1].x, qx[m][1].y, qx[m][2].x};
           KpRec r;
-          kp_build_rec(g, qs5, c.qs[2].y, c.qvf, qx5, r);
+          kp_build_rec(g, qs5, c.qs[2].y, c.qvf, qx[m], r);
           const bool on = CONN ? (c.use & 4) != 0 : true;
           kp_term(r, c.f[2].n, on ? c.f[2].a : 0.0, on ? c.f[2].ad : 0.0, true, FWD, acc);
         }
@@ -582,15 +594,38 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) xn[e] = ov[e] + acc[e] * ainv;
         }
-        xst[m][0] = make_double2(xn[0], xn[1]);
-        xst[m][1] = make_double2(xn[2], xn[3]);
-        xst[m][2] = make_double2(xn[4], ainv);
-        pst[m] = (unsigned)c.pos * 16u;
-        if (!KP_DEFER) store_x();     // on its way while the record is formed
+        // the launch's tag goes into every double; one 16-byte write-through (sc1) store
+        // per pair: what an agent-scope atomic store lowers to, at twice the width HIP's
+        // atomics offer; on its way while the record is formed
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) xn[e] = kp_tagged(xn[e], kp.tag);
+        if (c.act) {
+          // Inline asm on purpose: the compiler's wait-count pass must NOT see these stores.
+          // With loads and stores pending together it stops counting and waits for
+          // everything (vmcnt(0)) -- the stores' acknowledgements included, which is a
+          // trip to memory and back.  Unseen, they cost a wait only where an OLDER
+          // operation is waited for, and the step is arranged so that there is none: the
+          // prefetch of the next diagonal is drained just above (it has had the whole step
+          // to land), and the next wait is the one for the next step's k-neighbours,
+          // a step from now.
+          typedef double v2d __attribute__((ext_vector_type(2)));
+          const unsigned po = (unsigned)c.pos * 16u;
+          const v2d v0 = {xn[0], xn[1]}, v1 = {xn[2], xn[3]}, v2 = {xn[4], ainv};
+          // (s_nop 4: the base may have been written by a v_readlane just before --
+          // VALU-writes-SGPR -> VMEM needs 5 wait states, and the compiler's hazard
+          // recogniser does not look inside inline asm)
+          asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1"
+                       :: "v"(po), "v"(v0), "s"(z.pab(PA_X + 0) + kbase * 16) : "memory");
+          asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1"
+                       :: "v"(po), "v"(v1), "s"(z.pab(PA_X + 1) + kbase * 16) : "memory");
+          asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1"
+                       :: "v"(po), "v"(v2), "s"(z.pab(PA_X + 2) + kbase * 16) : "memory");
+        }
         // hand-over to the next diagonal through LDS
         const double s5[AGX_NEQ] = {c.s[0].x, c.s[0].y, c.s[1].x, c.s[1].y, c.s[2].x};
         KpRec r;
         kp_build_rec(g, s5, c.s[2].y, c.vf, xn, r);
+        if (c.act) {
         double* wp = lw + (c.j - jmin + 1);
 #pragma unroll
         for (int e = 0; e < AGX_NEQ; ++e) wp[e * nsl] = xn[e];
@@ -598,38 +633,16 @@ k_lusgs_kp(KpBlk b, KpGas g, int viscous, int nsl, KpArgs kp) {
         wp[9 * nsl] = r.p1; wp[10 * nsl] = r.h1;
         wp[11 * nsl] = r.r0; wp[12 * nsl] = r.v0[0]; wp[13 * nsl] = r.v0[1]; wp[14 * nsl] = r.v0[2];
         wp[15 * nsl] = r.p0; wp[16 * nsl] = r.h0; wp[17 * nsl] = r.cs; wp[18 * nsl] = r.vf;
+        }
       }
       jmin_prev = jmin;
       }
-      // every wave drains its stores, then the barrier, then ONE lane publishes
-      KP_STAMP(2);
-      // (the builtin lets the compiler's own scoreboard see the wait, so that it
-      // does not wait again -- behind the flag store -- before the register
-      // rotation below; the asm form is the one it can neither move nor drop)
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      KP_STAMP(3);
-      if (tid == 0 && has_pre && t + 1 + KP_QX_AHEAD < nsteps) wait_for(kq, t + 2 + KP_QX_AHEAD);
       KP_STAMP(4);
-      __syncthreads();
-      KP_STAMP(5);
+      __syncthreads();          // the records of this diagonal are in place
       if (!s_ok) return;
-      const int vis = KP_DEFER ? t : min(t + 1, nsteps);   // diagonals whose x has landed
-      if (tid == 0 && vis > 0) {
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        __hip_atomic_store(kp.flags + k * KP_FLAG_STRIDE, ebase + vis, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (t + 1 < nsteps) {
 #pragma unroll
-        for (int m = 0; m < CH; ++m) {
-          cur[m] = nxt[m];
-          if (KP_QX_AHEAD) {
-#pragma unroll
-            for (int h = 0; h < 3; ++h) qx[m][h] = qxn[m][h];
-          }
-        }
-      }
+      for (int m = 0; m < CH; ++m) cur[m] = nxt[m];
+      KP_STAMP(5);
     }
   }
 }

@@ -30,6 +30,13 @@ enum { VS_S0 = 0, VS_SM = 4, VS_SP = 8, VS_AI0 = 12, VS_AJ0 = 15, VS_AJ1 = 18, V
        VS_AK1 = 24, VS_VOL = 27, VS_WJ = 28, VS_RHO = 29, VS_MU = 30, VS_AI1 = 31, VS_WI = 34,
        VS_FJ = 35, VS_COUNT = 39 };
 
+// VT_LDSAREA: the area vectors of the faces at i+1 / j+1 are the neighbour lane's / row's
+// own lower-face vectors, already in its LDS slots; only lane 63 / row 7 (whose
+// neighbour belongs to the next tile) fetch them from memory (0: every thread loads them:
+// eight more loads per thread and step, of 29)
+#ifndef VT_LDSAREA
+#define VT_LDSAREA 1
+#endif
 #ifndef VT_EDGE_BARRIER
 #define VT_EDGE_BARRIER __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -146,12 +153,28 @@ __device__ __forceinline__ void vt_face(VShared sh, const GasDev& g, const VRef&
   f[3] = dot3(tau, vf) + kk * tg;
 }
 
+// Persistent: one workgroup per CU; the (column tile, k) steps of the block form one linear
+// sequence cut into gridDim.x equal ranges (a range that crosses into the next column
+// re-primes its window there), so all CUs finish together whatever the block shape --
+// with a grid of (tiles x k-chunks) workgroups at one workgroup per CU the last round ran
+// a fifth full.  Workgroup n runs on XCD n % 8: ranges are dealt so that each XCD's L2
+// sees neighbouring columns.
 __global__ void __launch_bounds__(VT_L * VT_R)
-k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
+k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
   __shared__ double sh[VT_R][VT_L][VS_COUNT];
   const int l = threadIdx.x, ty = threadIdx.y;
-  const int ci = blockIdx.x * VT_OI - 1 + l, cj = blockIdx.y * VT_OJ - 1 + ty;
-  const int k0 = blockIdx.z * kchunk, k1 = min(k0 + kchunk, b.nk);
+  const long S = (long)gx * gy * b.nk;
+  const int P = gridDim.x;
+  const int rr = P % 8 == 0 ? (int)(blockIdx.x % 8) * (P / 8) + (int)(blockIdx.x / 8)
+                            : (int)blockIdx.x;
+  long s_pos = S * rr / P;
+  const long s_end = S * (rr + 1) / P;
+  while (s_pos < s_end) {
+  const int col = (int)(s_pos / b.nk);
+  const int k0 = (int)(s_pos - (long)col * b.nk);
+  const int k1 = (int)min((long)b.nk, k0 + (s_end - s_pos));
+  s_pos += k1 - k0;
+  const int ci = (col % gx) * VT_OI - 1 + l, cj = (col / gx) * VT_OJ - 1 + ty;
   const bool inner = l >= 1 && l <= VT_OI && ty >= 1 && ty <= VT_OJ;
   const bool own = inner && ci < b.ni && cj < b.nj;
   // lower i-face: own cell or the owned cell to the left; lower j-face likewise
@@ -196,7 +219,7 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
   // thread's own LDS slots; registers hold only what nobody else reads.  kk starts
   // one plane early: the first pass only forms the k-face below the chunk ----
   int kk = k0 - 1;
-  double R1, MU1, V1, WK0, WK1, AK2[3], AIp[3], AJp[3];
+  double R1, MU1, V1, WK0, WK1, AK2[3], AIp[3] = {0, 0, 0}, AJp[3] = {0, 0, 0};
   {
     double t4[4], t3[3], r, m;
     const unsigned qk = qc + (unsigned)kk * sk;
@@ -212,8 +235,8 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
     ld_avec(2, qk, t3); PUT3(VS_AK0, t3);
     ld_avec(2, qk + sk, t3); PUT3(VS_AK1, t3);
     ld_avec(2, qc + (unsigned)min(kk + 2, kfmax) * sk, AK2);
-    ld_avec(0, qk + 8, AIp);
-    ld_avec(1, qk + sj, AJp);
+    if (!VT_LDSAREA || l == VT_L - 1) ld_avec(0, qk + 8, AIp);
+    if (!VT_LDSAREA || ty == VT_R - 1) ld_avec(1, qk + sj, AJp);
     sh[ty][l][VS_VOL] = b.ldb(PL_VOL, qk); V1 = b.ldb(PL_VOL, qk + sk);
     WK0 = b.ldb(PL_WID + 2, qk); WK1 = b.ldb(PL_WID + 2, qk + sk);
     sh[ty][l][VS_WI] = b.ldb(PL_WID + 0, qk); sh[ty][l][VS_WJ] = b.ldb(PL_WID + 1, qk);
@@ -233,6 +256,7 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
     if (do_i && !pre) {
       double aF[3], aFm[3];
       vt_ld3(sh, VRef{VS_AI0, ty, l}, aF); vt_ld3(sh, VRef{VS_AI0, ty, ll}, aFm);
+      if (VT_LDSAREA && l < VT_L - 1) vt_ld3(sh, VRef{VS_AI0, ty, lr}, AIp);
       const VtEdge ju{{VS_S0, tu, l}, {VS_S0, tu, ll}, {VS_AJ0, tu, l}, {VS_AJ0, tu, ll}};
       const VtEdge jl{{VS_S0, td, l}, {VS_S0, td, ll}, {VS_AJ0, ty, l}, {VS_AJ0, ty, ll}};
       const VtEdge ku{meP, {VS_SP, ty, ll}, {VS_AK1, ty, l}, {VS_AK1, ty, ll}};
@@ -251,6 +275,7 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
     if (do_j && !pre) {
       double aF[3], aFm[3];
       vt_ld3(sh, VRef{VS_AJ0, ty, l}, aF); vt_ld3(sh, VRef{VS_AJ0, td, l}, aFm);
+      if (VT_LDSAREA && ty < VT_R - 1) vt_ld3(sh, VRef{VS_AJ0, tu, l}, AJp);
       const VtEdge iu{{VS_S0, ty, lr}, {VS_S0, td, lr}, {VS_AI0, ty, lr}, {VS_AI0, td, lr}};
       const VtEdge il{{VS_S0, ty, ll}, {VS_S0, td, ll}, {VS_AI0, ty, l}, {VS_AI0, td, l}};
       const VtEdge ku{meP, {VS_SP, td, l}, {VS_AK1, ty, l}, {VS_AK1, td, l}};
@@ -279,15 +304,15 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
     // ---- request the plane that enters the window next step (after the faces:
     // together with their operands it does not fit the register file; in flight
     // during the barrier and the residual update) ----
-    double nS[4], nR, nMU, nAI[3], nAJ[3], nAK[3], nAIp[3], nAJp[3];
+    double nS[4], nR, nMU, nAI[3], nAJ[3], nAK[3], nAIp[3] = {0, 0, 0}, nAJp[3] = {0, 0, 0};
     const unsigned qn = qc + (unsigned)(kk + 1) * sk;            // plane kk+1 (always valid)
     const unsigned qn2 = qc + (unsigned)min(kk + 2, kcmax) * sk; // cells of plane kk+2
     ld_state(kk + 2, nS, nR, nMU);
     ld_avec(0, qn2, nAI);
     ld_avec(1, qn2, nAJ);
     ld_avec(2, qc + (unsigned)min(kk + 3, kfmax) * sk, nAK);
-    ld_avec(0, qn + 8, nAIp);
-    ld_avec(1, qn + sj, nAJp);
+    if (!VT_LDSAREA || l == VT_L - 1) ld_avec(0, qn + 8, nAIp);
+    if (!VT_LDSAREA || ty == VT_R - 1) ld_avec(1, qn + sj, nAJp);
     const double nV = b.ldb(PL_VOL, qn2), nWK = b.ldb(PL_WID + 2, qn2);
     const double nwi = b.ldb(PL_WID + 0, qn), nwj = b.ldb(PL_WID + 1, qn);
     __syncthreads();                           // all faces done: the windows may rotate
@@ -343,6 +368,8 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int kchunk) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) { AK2[c] = nAK[c]; AIp[c] = nAIp[c]; AJp[c] = nAJp[c]; }
     }
+  }
+  __syncthreads();   // segment boundary: the windows are primed afresh
   }
 }
 

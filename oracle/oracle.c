@@ -21,6 +21,10 @@
  * for the whole library (test infrastructure, single-threaded): ora_config_set
  * refuses a second live context with another count.  NEQM sizes local arrays, NF is
  * the flow block of the block-matrix solvers. */
+/* blocks smaller than this stay on one thread (the parity tests' blocks: a parallel region
+ * per hyperplane costs more than it saves, and far more on an oversubscribed host) */
+static long g_omp_min_cells = 40000L;   /* ORA_OMP_MIN_CELLS (read by ora_ctx_create) */
+#define OMP_MIN_CELLS g_omp_min_cells
 static int g_neq = 5, g_live_cfg = 0;
 #define NEQ g_neq
 #define NEQM 7
@@ -1528,7 +1532,7 @@ static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
    * receives its contributions in the serial order: the result does not depend on
    * the number of threads */
   const int n_outer = d == 2 ? b->nj : b->nk, n_inner = d == 2 ? b->nk + 1 : b->nj + o[1];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)
   for (int outer = 0; outer < n_outer; ++outer)
     for (int inner = 0; inner < n_inner; ++inner)
       for (int i = 0; i < b->ni + o[0]; ++i) {
@@ -1591,7 +1595,7 @@ static void calc_inv_flux(ora_ctx *c, blk_t *b, int d) {
 
 /* procBlock::UpdateAuxillaryVariables procBlock.cpp:6171-6189 */
 static void update_aux(ora_ctx *c, blk_t *b) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)
   for (int k = -b->ng; k < b->nk + b->ng; ++k)
     for (int j = -b->ng; j < b->nj + b->ng; ++j)
       for (int i = -b->ng; i < b->ni + b->ng; ++i) {
@@ -1931,7 +1935,7 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
    * receives its contributions in the serial order: the result does not depend on
    * the number of threads */
   const int n_outer = d == 2 ? b->nj : b->nk, n_inner = d == 2 ? b->nk + 1 : b->nj + o[1];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)
   for (int outer = 0; outer < n_outer; ++outer)
     for (int inner = 0; inner < n_inner; ++inner)
       for (int i = 0; i < b->ni + o[0]; ++i) {
@@ -2090,7 +2094,7 @@ static void calc_visc_flux(ora_ctx *c, blk_t *b, int d) {
 static void calc_src_terms(ora_ctx *c, blk_t *b) {
   const int implicit = c->cfg.time_integration >= AGX_TIME_IMPLICIT_EULER;
   const double invScaling = 1.0 / c->scaling;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
@@ -2226,7 +2230,7 @@ static void update_block(ora_ctx *c, blk_t *b, int rr, double *l2,
    * number of threads) */
   double *pl2 = (double *)calloc((size_t)b->nk * NEQM, sizeof(double));
   agx_linf *plinf = (agx_linf *)malloc((size_t)b->nk * sizeof(agx_linf));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)
   for (int k = 0; k < b->nk; ++k) {
     double *l2k = pl2 + (size_t)k * NEQM;
     agx_linf *lk = plinf + k;
@@ -2435,7 +2439,7 @@ static void apply_ainv(const ora_ctx *c, const blk_t *b, long p, const double *v
 }
 static int implicit_begin(ora_ctx *c, blk_t *b) {
   int singular = 0;
-#pragma omp parallel for schedule(static) reduction(|:singular)
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS) reduction(|:singular)
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
@@ -2473,7 +2477,7 @@ static int implicit_begin(ora_ctx *c, blk_t *b) {
       }
   if (singular) return fail("Singular matrix in Gauss-Jordan elimination!");
   if (requires_init(c)) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)
     for (int k = 0; k < b->nk; ++k)
       for (int j = 0; j < b->nj; ++j)
         for (int i = 0; i < b->ni; ++i) {
@@ -2493,7 +2497,7 @@ static int implicit_begin(ora_ctx *c, blk_t *b) {
 static void lusgs_forward(ora_ctx *c, blk_t *b, int sweep) {
   const int nplanes = b->ni + b->nj + b->nk - 2;
   for (int pp = 0; pp < nplanes; ++pp)
-#pragma omp parallel for schedule(static)   /* the cells of a hyperplane are independent */
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)   /* the cells of a hyperplane are independent */
     for (int k = 0; k < b->nk; ++k)
       for (int j = 0; j < b->nj; ++j) {
         const int i = pp - j - k;
@@ -2515,7 +2519,7 @@ static void lusgs_forward(ora_ctx *c, blk_t *b, int sweep) {
 static void lusgs_backward(ora_ctx *c, blk_t *b, int sweep) {
   const int nplanes = b->ni + b->nj + b->nk - 2;
   for (int pp = nplanes - 1; pp >= 0; --pp)
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)
     for (int k = b->nk - 1; k >= 0; --k)
       for (int j = b->nj - 1; j >= 0; --j) {
         const int i = pp - j - k;
@@ -2539,7 +2543,7 @@ static void lusgs_backward(ora_ctx *c, blk_t *b, int sweep) {
 /* dplur::DPLUR linearSolver.cpp:473-507 */
 static void dplur_sweep(ora_ctx *c, blk_t *b) {
   memcpy(b->xold, b->x, sizeof(double) * NEQ * b->ncell_g);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
@@ -2558,7 +2562,7 @@ static void dplur_sweep(ora_ctx *c, blk_t *b) {
  * mgSolution::CycleAtLevel mgSolution.cpp:198-206 */
 static void matrix_residual(ora_ctx *c, blk_t *b, double *sumsq, long *size) {
   double *part = (double *)calloc((size_t)b->nk, sizeof(double));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
@@ -2593,6 +2597,7 @@ const char *ora_last_error(void) { return g_err; }
 const char *ora_version(void) { return "aither-oracle 0.1 (CPU restatement)"; }
 
 int ora_ctx_create(int device, int rank, ora_ctx **out) {
+  if (getenv("ORA_OMP_MIN_CELLS")) g_omp_min_cells = atol(getenv("ORA_OMP_MIN_CELLS"));
   (void)device;
   ora_ctx *c = (ora_ctx *)calloc(1, sizeof *c);
   if (!c) return fail("out of memory");

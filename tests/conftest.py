@@ -10,6 +10,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the oracle is threaded (OpenMP) for blocks of bench size; a test box may show far more
+# cores than it may use, so the tests fix the thread count (read when libgomp loads)
+os.environ.setdefault("OMP_NUM_THREADS", "8")
 
 
 def pytest_configure(config):

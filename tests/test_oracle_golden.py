@@ -62,6 +62,7 @@ def test_oracle_does_not_depend_on_the_thread_count(oracle, kind):
                       matrix_solver="dplur", matrix_sweeps=3, cfl=5.0),
     }[kind]
     out = []
+    os.environ["ORA_OMP_MIN_CELLS"] = "0"      # thread even these small blocks
     for nthreads in (1, 5):
         gomp.omp_set_num_threads(nthreads)
         case = synthetic.single_block_case((13, 11, 9), stretch=1.2, **kw)
@@ -71,7 +72,8 @@ def test_oracle_does_not_depend_on_the_thread_count(oracle, kind):
         out.append((sol.download("state", 0).copy(), np.array(sol.history[-1]["l2"]),
                     sol.history[-1]["matrix"]))
         sol.close()
-    gomp.omp_set_num_threads(max(1, os.cpu_count() or 1))
+    os.environ.pop("ORA_OMP_MIN_CELLS")
+    gomp.omp_set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "8")))
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
     assert out[0][2] == out[1][2]

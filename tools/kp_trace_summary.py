@@ -20,6 +20,8 @@ for hdr, rows in blocks[:int(sys.argv[2]) if len(sys.argv) > 2 else 2]:
         seg = d[lo:hi]
         if len(seg) == 0:
             continue
-        print(f"  steps {lo}-{hi}: issue {seg[:,0].mean():.0f} compute {seg[:,1].mean():.0f} "
-              f"vmcnt {seg[:,2].mean():.0f} poll {seg[:,3].mean():.0f} barrier {seg[:,4].mean():.0f}"
-              f"  step {step[lo:hi].mean():.0f} ns")
+        # stamps (k_lusgs_kp): 0 top, 1 requests issued, 2 in-plane terms done, 3 the
+        # k-neighbours' x has landed, 4 k-term + stores + record done, 5 barrier + rotation
+        print(f"  steps {lo}-{hi}: issue {seg[:,0].mean():.0f} in-plane {seg[:,1].mean():.0f} "
+              f"poll {seg[:,2].mean():.0f} k-term+store+record {seg[:,3].mean():.0f} "
+              f"barrier+rotate {seg[:,4].mean():.0f}  step {step[lo:hi].mean():.0f} ns")
