@@ -149,11 +149,15 @@ struct agx_ctx {
   size_t blocks_tab_n = 0;
   hipGraphExec_t sweep_graph_all[2][2][2] = {};
   int mresid_split = 1;      // bands of diagonals per XCD in k_matrix_resid_d2 (AGX_MRESID_SPLIT)
+  bool mresid_march = true;  // AGX_MRESID=plane: one plane position per thread (comparison form)
   bool have_time_n = false;  // agx_store_time_n has run (nonreflecting BCs read consVarsN)
   // agx_iterate fills the ghost cells for the NEXT call right after the update,
   // behind the norm read-back the host waits for, so that the GPU does not idle
   // while the host turns the iteration around
   bool in_iterate = false, ghosts_prefilled = false;
+  // inside agx_iterate the matrix residual is not read back by a host synchronisation of
+  // its own (the update would wait for the host): it rides with the update's norms
+  bool mres_deferred = false;
   hipEvent_t norm_event = nullptr;
   bool consn_pending = false;   // AssignSolToTimeN deferred into the first residual launch of the step
   bool state_is_time_n = false; // nothing has changed the state since agx_store_time_n
@@ -858,16 +862,16 @@ int bc_pass(agx_ctx* c, bool faces, int viscous) {
   return 0;
 }
 
-int reduce_norms(agx_ctx* c, size_t blk_index, long nparts) {
+int reduce_norms(agx_ctx* c, size_t blk_index, long nparts, NormPartial* out = nullptr) {
+  if (!out) out = c->norm_out + blk_index;
   if (nparts > 4096) {
     // two levels: 64 workgroups fold slices into the scratch behind norm_out
     NormPartial* tmp = c->norm_out + c->blocks.size();
     hipLaunchKernelGGL(k_norm_final, dim3(64), dim3(256), 0, c->stream, c->partials, nparts, tmp);
-    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, c->stream, tmp, 64L,
-                       c->norm_out + blk_index);
+    hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, c->stream, tmp, 64L, out);
   } else {
     hipLaunchKernelGGL(k_norm_final, dim3(1), dim3(256), 0, c->stream,
-                       c->partials, nparts, c->norm_out + blk_index);
+                       c->partials, nparts, out);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -921,6 +925,10 @@ int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
   HIPCHK(hipMemcpyAsync(c->norm_host, c->norm_out,
                         sizeof(NormPartial) * c->blocks.size(),
                         hipMemcpyDeviceToHost, c->stream));
+  if (c->mres_deferred)
+    HIPCHK(hipMemcpyAsync(c->norm_host + c->blocks.size(), c->norm_out + c->blocks.size() + 64,
+                          sizeof(NormPartial) * c->blocks.size(), hipMemcpyDeviceToHost,
+                          c->stream));
   HIPCHK(hipMemcpyAsync(c->err_host, c->err_dev, sizeof(int),
                         hipMemcpyDeviceToHost, c->stream));
   if (c->in_iterate && mode != 2 && c->eager_ghosts) {
@@ -993,6 +1001,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_SWEEP_THREE")) c->sweep_three = atoi(w) != 0;
     if (const char* w = getenv("AGX_SWEEP_RECORDS")) c->sweep_records = atoi(w) != 0;
     if (const char* w = getenv("AGX_MRESID_SPLIT")) c->mresid_split = std::min(64, std::max(1, atoi(w)));
+    if (const char* w = getenv("AGX_MRESID")) c->mresid_march = strcmp(w, "plane") != 0;
   }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
   HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
@@ -1351,8 +1360,10 @@ int agx_conn_create(agx_ctx* c, const agx_connection* cc, int* conn_id) {
 }
 
 // workgroups of k_matrix_resid_d2: 8 XCDs x mresid_split bands x chunks per band x nk
+constexpr int MRESID_KC = 32;   // planes a workgroup of k_matrix_resid_d2m marches
 long mresid_wgs(const agx_ctx* c, const BlockDev& b) {
   const long nchunk = ((long)b.d2.Pi * b.d2.Pj + 255) / 256;
+  if (c->mresid_march) return 8L * ((nchunk + 7) / 8) * ((b.nk + MRESID_KC - 1) / MRESID_KC);
   const long bands = 8L * c->mresid_split;
   return bands * ((nchunk + bands - 1) / bands) * b.nk;
 }
@@ -1463,8 +1474,10 @@ int agx_setup_finalize(agx_ctx* c) {
   c->n_partials = max_parts;
   HIPCHK(hipMalloc((void**)&c->partials, sizeof(NormPartial) * max_parts));
   const size_t nb = std::max<size_t>(c->blocks.size(), 1);
-  HIPCHK(hipMalloc((void**)&c->norm_out, sizeof(NormPartial) * (nb + 64)));
-  HIPCHK(hipHostMalloc((void**)&c->norm_host, sizeof(NormPartial) * nb));
+  // [0, nb): norms of the update; [nb, nb + 64): scratch of the two-level fold;
+  // [nb + 64, 2 nb + 64): the matrix residual (read back with the update's norms)
+  HIPCHK(hipMalloc((void**)&c->norm_out, sizeof(NormPartial) * (2 * nb + 64)));
+  HIPCHK(hipHostMalloc((void**)&c->norm_host, sizeof(NormPartial) * 2 * nb));
   c->finalized = true;
   return 0;
 }
@@ -1757,40 +1770,57 @@ int agx_phase_relax_backward(agx_ctx* c, int sweep) {
   return 0;
 }
 
-int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
+namespace {
+void matrix_residual_fold(agx_ctx* c, const NormPartial* host, double* mr) {
   double sumsq = 0.0;
   long size = 0;
+  for (size_t n = 0; n < c->blocks.size(); ++n) {
+    const BlockDev& b = c->blocks[n].d;
+    for (int e = 0; e < AGX_NEQ; ++e) sumsq += host[n].l2[e];
+    // mr.Size(): ghost-inclusive (linearSolver.cpp:66-68, mgSolution.cpp:203)
+    size += (long)AGX_NEQ * (b.ni + 2 * b.ng) * (b.nj + 2 * b.ng) * (b.nk + 2 * b.ng);
+  }
+  *mr = size > 0 ? sumsq / (double)size : 0.0;
+}
+}  // namespace
+
+int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
+  const bool defer = c->in_iterate;      // agx_iterate reads it back with the update's norms
+  NormPartial* out = c->norm_out + (defer ? c->blocks.size() + 64 : 0);
   {
     Timer t(c, G_MRESID);
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       const BlockDev& b = c->blocks[n].d;
 #if AGX_FAST
       if (b.d2.base) {
-        // (position chunk, k) pairs dealt to the XCDs band by band, see the kernel
+        // (position chunk, k) pairs dealt to the XCDs band by band, see the kernels
         const long nwg = mresid_wgs(c, b);
-        hipLaunchKernelGGL(k_matrix_resid_d2, dim3((unsigned)nwg), dim3(256), 0, c->stream, b,
-                           c->gas, c->sp, c->mresid_split, c->partials);
-        if (reduce_norms(c, n, nwg)) return 1;
+        if (c->mresid_march)
+          hipLaunchKernelGGL(k_matrix_resid_d2m, dim3((unsigned)nwg), dim3(256), 0, c->stream, b,
+                             c->gas, c->sp, MRESID_KC, c->partials);
+        else
+          hipLaunchKernelGGL(k_matrix_resid_d2, dim3((unsigned)nwg), dim3(256), 0, c->stream, b,
+                             c->gas, c->sp, c->mresid_split, c->partials);
+        if (reduce_norms(c, n, nwg, out + n)) return 1;
         continue;
       }
 #endif
       const dim3 grid = cell_grid(b, CELL_BLOCK);
       hipLaunchKernelGGL(k_matrix_resid, grid, CELL_BLOCK, 0, c->stream, b,
                          c->gas, c->sp, c->partials);
-      if (reduce_norms(c, n, (long)grid.x * grid.y * grid.z)) return 1;
+      if (reduce_norms(c, n, (long)grid.x * grid.y * grid.z, out + n)) return 1;
     }
+  }
+  if (defer) {
+    c->mres_deferred = true;
+    *mr = 0.0;
+    return 0;
   }
   HIPCHK(hipMemcpyAsync(c->norm_host, c->norm_out,
                         sizeof(NormPartial) * c->blocks.size(),
                         hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (size_t n = 0; n < c->blocks.size(); ++n) {
-    const BlockDev& b = c->blocks[n].d;
-    for (int e = 0; e < AGX_NEQ; ++e) sumsq += c->norm_host[n].l2[e];
-    // mr.Size(): ghost-inclusive (linearSolver.cpp:66-68, mgSolution.cpp:203)
-    size += (long)AGX_NEQ * (b.ni + 2 * b.ng) * (b.nj + 2 * b.ng) * (b.nk + 2 * b.ng);
-  }
-  *mr = size > 0 ? sumsq / (double)size : 0.0;
+  matrix_residual_fold(c, c->norm_host, mr);
   return 0;
 }
 
@@ -2065,6 +2095,9 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
     AGX_XCHG(AGX_HALO_UPDATE);
     AGX_PHASE(agx_phase_matrix_residual(c, matrix_resid));
     AGX_PHASE(agx_phase_implicit_update(c, mm, l2, linf));
+    if (!st && c->mres_deferred)      // came back with the update's norms
+      matrix_residual_fold(c, c->norm_host + c->blocks.size(), matrix_resid);
+    c->mres_deferred = false;
   } else {
     AGX_PHASE(agx_phase_explicit_update(c, mm, l2, linf));
   }

@@ -161,6 +161,40 @@ def test_lusgs_sweep_forms_agree(agx, sweeps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["single", "stacked"])
+def test_matrix_residual_forms_agree(agx, kind):
+    """The matrix residual marching along k (default: the k-neighbours of a plane position
+    stay in registers) and with one plane position per thread (AGX_MRESID=plane) are the
+    same sum in the same order per cell; 70 planes = three k-chunks of the marching form, a
+    ragged last chunk of plane positions, and -- stacked -- ghost cells across a connection
+    as k-neighbours."""
+    wall = {3: ("viscousWall", 2), 1: ("characteristic", 1),
+            2: ("characteristic", 1), 4: ("characteristic", 1)}
+    kw = dict(stretch=1.1, bcs=wall, equation_set="navierStokes",
+              time_integration="implicitEuler", matrix_solver="lusgs", matrix_sweeps=2, cfl=5.0)
+    if kind == "single":
+        case = synthetic.single_block_case(n=(19, 11, 70), **kw)
+    else:
+        case = synthetic.stacked_blocks_case(n=(13, 9, 35), nblocks=2, axis="k", **kw)
+    out = {}
+    for form in ("march", "plane"):
+        old = os.environ.get("AGX_MRESID")
+        os.environ["AGX_MRESID"] = form
+        try:
+            s = Solver(agx, case)
+        finally:
+            if old is None:
+                os.environ.pop("AGX_MRESID", None)
+            else:
+                os.environ["AGX_MRESID"] = old
+        s.step(0), s.step(1)
+        out[form] = [h["matrix"] for h in s.history]
+        s.close()
+    assert all(m > 0.0 for m in out["march"])
+    assert np.allclose(out["march"], out["plane"], rtol=1e-12, atol=0.0), out
+
+
+@pytest.mark.gpu
 def test_lusgs_spin_limit_error_path(agx, oracle):
     """A k-plane that waits longer than AGX_SPIN_LIMIT polls for its predecessor
     raises the error flag, the grid drains, agx_iterate returns the error -- and a
