@@ -24,6 +24,20 @@ FIELD = {"state": 0, "residual": 1, "dt": 2, "spec_radius": 3, "cons_n": 4,
          "cons_nm1": 9, "vel_grad": 10, "temp_grad": 11, "dens_grad": 12,
          "press_grad": 13}
 HALO_STATE, HALO_UPDATE, HALO_VELGRAD_A, HALO_VELGRAD_B, HALO_TURB = 0, 1, 2, 3, 4
+# variables of a function file (AGX_OUT_*), under the reference's names (output.cpp:235-407)
+OUT = {"density": 0, "vel_x": 1, "vel_y": 2, "vel_z": 3, "pressure": 4, "mach": 5, "sos": 6,
+       "dt": 7, "temperature": 8, "energy": 9, "enthalpy": 10, "cp": 11, "cv": 12, "rank": 13,
+       "globalPosition": 14, "viscosityRatio": 15, "turbulentViscosity": 16, "viscosity": 17,
+       "tke": 18, "sdr": 19, "f1": 20, "f2": 21, "wallDistance": 22}
+for _n, _base in (("velGrad", 23),):
+    for _q, _c in enumerate(("ux", "vx", "wx", "uy", "vy", "wy", "uz", "vz", "wz")):
+        OUT[f"{_n}_{_c}"] = _base + _q
+for _n, _base in (("tempGrad", 32), ("densityGrad", 35), ("pressGrad", 38), ("tkeGrad", 41),
+                  ("omegaGrad", 44)):
+    for _q, _c in enumerate("xyz"):
+        OUT[f"{_n}_{_c}"] = _base + _q
+for _q, _c in enumerate(("mass", "mom_x", "mom_y", "mom_z", "energy", "tke", "sdr")):
+    OUT[f"resid_{_c}"] = 47 + _q
 
 c_dp = C.POINTER(C.c_double)
 
@@ -119,6 +133,8 @@ SYMBOLS = {
     "state_upload": (_i, [_vp, _i, c_dp]),
     "field_download": (_i, [_vp, _i, _i, c_dp]),
     "field_upload": (_i, [_vp, _i, _i, c_dp]),
+    "output_pack": (_i, [_vp, _i, _i, C.POINTER(C.c_int32), c_dp]),
+    "restart_pack": (_i, [_vp, _i, _i, c_dp]),
     "store_time_n": (_i, [_vp, _i]),
     "iterate": (_i, [_vp, _i, C.c_double, c_dp, C.POINTER(Linf), c_dp]),
     "phase_bc_faces": (_i, [_vp]),

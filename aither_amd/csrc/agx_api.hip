@@ -1538,14 +1538,14 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
     // cell-centre gradients: formed on demand into a temporary (an output path)
     const long ncell = (long)b.d.ni * b.d.nj * b.d.nk;
     double* tmp = nullptr;
-    if (stage_buffer(c, (size_t)18 * ncell, &tmp)) return 1;
+    if (stage_buffer(c, (size_t)3 * NGF * ncell, &tmp)) return 1;
     hipLaunchKernelGGL(k_cell_grads, cell_grid(b.d, CELL_BLOCK), CELL_BLOCK, 0, c->stream, b.d,
                        c->gas, tmp);
     HIPCHK(hipGetLastError());
     const int off = field == AGX_FIELD_VEL_GRAD ? 0 : 9 + 3 * (field - AGX_FIELD_TEMP_GRAD);
     const int nc = field == AGX_FIELD_VEL_GRAD ? 9 : 3;
     // strided device -> host copy of the requested columns
-    HIPCHK(hipMemcpy2DAsync(out, sizeof(double) * nc, tmp + off, sizeof(double) * 18,
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(double) * nc, tmp + off, sizeof(double) * 3 * NGF,
                             sizeof(double) * nc, ncell, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -1569,6 +1569,69 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
   const int g = gh ? b.d.ng : 0;
   return download_aos(c, b, out, p, nc, b.d.ni + 2 * g, b.d.nj + 2 * g, b.d.nk + 2 * g, g);
 }
+// ---- output: WriteFunFile / WriteRestart payloads packed on the device ------
+namespace {
+OutSpec out_spec(const agx_ctx* c, const Block& b) {
+  OutSpec sp;
+  memset(&sp, 0, sizeof sp);
+  const agx_gas& a = c->cfg.gas;
+  sp.rho_ref = a.rho_ref; sp.a_ref = a.a_ref; sp.l_ref = a.l_ref; sp.t_ref = a.t_ref;
+  sp.mu_ref = c->gas.mu_ref;                  // transport::MuRef, transport.cpp:58-66
+  sp.rank = c->rank;
+  sp.global_pos = b.global_pos;
+  return sp;
+}
+}  // namespace
+
+int agx_output_pack(agx_ctx* c, int id, int nvar, const int32_t* vars, double* out) {
+  if (flush_consn(c)) return 1;
+  if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
+  if (nvar < 1 || nvar > AGX_OUT_COUNT) return fail("agx_output_pack: nvar %d out of range", nvar);
+  Block& b = c->blocks[id];
+  OutSpec sp = out_spec(c, b);
+  sp.nvar = nvar;
+  bool need_grads = false;
+  for (int v = 0; v < nvar; ++v) {
+    if (vars[v] < 0 || vars[v] >= AGX_OUT_COUNT) return fail("unknown output variable %d", vars[v]);
+    if (vars[v] == AGX_OUT_VISCOSITY && !c->sp.viscous)
+      return fail("viscosity_ is only kept for viscous runs (procBlock.cpp:6171)");
+    sp.var[v] = vars[v];
+    need_grads = need_grads || (vars[v] >= AGX_OUT_VELGRAD && vars[v] < AGX_OUT_RESID);
+  }
+  const long ncell = (long)b.d.ni * b.d.nj * b.d.nk;
+  double* tmp = nullptr;
+  const size_t gdoubles = need_grads ? (size_t)3 * NGF * ncell : 0;
+  if (stage_buffer(c, gdoubles + (size_t)nvar * ncell, &tmp)) return 1;
+  if (need_grads)
+    hipLaunchKernelGGL(k_cell_grads, cell_grid(b.d, CELL_BLOCK), CELL_BLOCK, 0, c->stream, b.d,
+                       c->gas, tmp);
+  double* packed = tmp + gdoubles;
+  hipLaunchKernelGGL(k_output_pack, cell_grid(b.d, CELL_BLOCK), CELL_BLOCK, 0, c->stream, b.d,
+                     c->gas, sp, need_grads ? tmp : nullptr, packed);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, packed, sizeof(double) * nvar * ncell, hipMemcpyDeviceToHost,
+                        c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int agx_restart_pack(agx_ctx* c, int id, int which, double* out) {
+  if (flush_consn(c)) return 1;
+  if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
+  if (which != 0 && which != 1) return fail("agx_restart_pack: which is 0 (state) or 1 (consVarsNm1)");
+  Block& b = c->blocks[id];
+  const long ncell = (long)b.d.ni * b.d.nj * b.d.nk;
+  double* tmp = nullptr;
+  if (stage_buffer(c, (size_t)(AGX_NEQ + 1) * ncell, &tmp)) return 1;
+  hipLaunchKernelGGL(k_restart_pack, cell_grid(b.d, CELL_BLOCK), CELL_BLOCK, 0, c->stream, b.d,
+                     out_spec(c, b), which, tmp);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, tmp, sizeof(double) * (AGX_NEQ + 1) * ncell, hipMemcpyDeviceToHost,
+                        c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
   c->ghosts_prefilled = false;
   c->state_is_time_n = false;

@@ -2753,14 +2753,17 @@ k_matrix_resid(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
 // cell (procBlock.cpp:1397-1449, CalcGradsI/J/K :5173-5786), six fields u, v, w,
 // T, rho, p.  Formed on demand; one thread per cell straight from the planes (an
 // output step, not the iteration).  out: [cell][18], physical cells, i fastest.
+// fields: u, v, w, T, rho, p and -- rans -- k, omega (tkeGrad_, omegaGrad_)
+constexpr int NGF = 6 + (AGX_NEQ - 5);
 __device__ __forceinline__ double grad_field(const BlockDev& b, const GasDev& g, long q, int f) {
   if (f < 3) return b.state[1 + f][q];
   if (f == 4) return b.state[0][q];
   if (f == 5) return b.state[4][q];
+  if (f >= 6) return b.state[AGX_NEQ > 5 ? f - 1 : 0][q];
   return b.state[4][q] / (b.state[0][q] * g.R);
 }
 __device__ inline void face_grad6(const BlockDev& b, const GasDev& g, int d, long qU,
-                                  double (*g6)[6]) {
+                                  double (*g6)[NGF]) {
   const long sd = b.stride(d), qL = qU - sd;
   double au[3][3], al[3][3];
   {
@@ -2778,7 +2781,7 @@ __device__ inline void face_grad6(const BlockDev& b, const GasDev& g, int d, lon
     for (int r = 0; r < 3; ++r) al[t][r] = 0.5 * (a0[r] + a1[r]);
   }
   const double inv_vol = 1.0 / (0.5 * (b.vol[qL] + b.vol[qU]));
-  for (int f = 0; f < 6; ++f) {
+  for (int f = 0; f < NGF; ++f) {
     double vu[3], vl[3];
     const double fL = grad_field(b, g, qL, f), fU = grad_field(b, g, qU, f);
     vl[d] = fL; vu[d] = fU;
@@ -2793,17 +2796,17 @@ __device__ inline void face_grad6(const BlockDev& b, const GasDev& g, int d, lon
                   vu[2] * au[2][r] - vl[2] * al[2][r]) * inv_vol;
   }
 }
+// acc: [3 NGF]; velocity gradient [3 r + c] first, then per field f >= 3 its three
+// derivatives at 9 + 3 (f - 3)
 __device__ inline void cell_grads18(const BlockDev& b, const GasDev& g, long q, double* acc) {
-  for (int n = 0; n < 18; ++n) acc[n] = 0.0;
+  for (int n = 0; n < 3 * NGF; ++n) acc[n] = 0.0;
   for (int d = 0; d < 3; ++d)
     for (int up = 0; up < 2; ++up) {
-      double g6[3][6];
+      double g6[3][NGF];
       face_grad6(b, g, d, q + (up ? b.stride(d) : 0), g6);
       for (int r = 0; r < 3; ++r) {
         for (int f = 0; f < 3; ++f) acc[3 * r + f] += (1.0 / 6.0) * g6[r][f];
-        acc[9 + r] += (1.0 / 6.0) * g6[r][3];
-        acc[12 + r] += (1.0 / 6.0) * g6[r][4];
-        acc[15 + r] += (1.0 / 6.0) * g6[r][5];
+        for (int f = 3; f < NGF; ++f) acc[9 + 3 * (f - 3) + r] += (1.0 / 6.0) * g6[r][f];
       }
     }
 }
@@ -2812,10 +2815,123 @@ __global__ void __launch_bounds__(256) k_cell_grads(BlockDev b, GasDev g, double
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
   if (i >= b.ni || j >= b.nj) return;
-  double acc[18];
+  double acc[3 * NGF];
   cell_grads18(b, g, b.idx(i, j, k), acc);
-  double* o = out + 18 * (((long)k * b.nj + j) * b.ni + i);
-  for (int n = 0; n < 18; ++n) o[n] = acc[n];
+  double* o = out + 3 * NGF * (((long)k * b.nj + j) * b.ni + i);
+  for (int n = 0; n < 3 * NGF; ++n) o[n] = acc[n];
+}
+
+// ---------------------------------------------------------------------------
+// Output: the per-cell variables of a function file, WriteFunFile (output.cpp:235-407),
+// formed and re-dimensionalised on the device; one thread per physical cell, variable by
+// variable into out[v * ncell + cell] (each store of a wave is a contiguous row).  grads:
+// k_cell_grads' output, or null when no gradient is asked for.
+struct OutSpec {
+  int nvar;
+  int var[AGX_OUT_COUNT];
+  double rho_ref, a_ref, l_ref, t_ref, mu_ref;
+  int rank, global_pos;
+};
+__global__ void __launch_bounds__(256)
+k_output_pack(BlockDev b, GasDev g, OutSpec sp, const double* __restrict__ grads,
+              double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  const long ncell = (long)b.ni * b.nj * b.nk, p = ((long)k * b.nj + j) * b.ni + i;
+  double s[AGX_NEQ];
+  load5(b.state, q, s);
+  const double rR = sp.rho_ref, aR = sp.a_ref, lR = sp.l_ref, tR = sp.t_ref, muR = sp.mu_ref;
+  // plain division / sqrt: an output path, the values go to a file
+  const double t = s[4] / (s[0] * g.R);
+  const double cs = sqrt(g.gamma * s[4] / s[0]);
+  const double v2 = dot3(s + 1, s + 1);
+  const double en = g.hf + g.n * s[4] / s[0] + 0.5 * v2;       // Energy: e(T) + |v|^2 / 2
+  for (int v = 0; v < sp.nvar; ++v) {
+    const int var = sp.var[v];
+    double val = 0.0;
+    switch (var) {
+      case AGX_OUT_DENSITY: val = s[0] * rR; break;
+      case AGX_OUT_VEL_X: val = s[1] * aR; break;
+      case AGX_OUT_VEL_Y: val = s[2] * aR; break;
+      case AGX_OUT_VEL_Z: val = s[3] * aR; break;
+      case AGX_OUT_PRESSURE: val = s[4] * rR * aR * aR; break;
+      case AGX_OUT_MACH: val = sqrt(v2) / cs; break;
+      case AGX_OUT_SOS: val = cs * aR; break;
+      case AGX_OUT_DT: val = b.dt[q] / (aR * lR); break;
+      case AGX_OUT_TEMPERATURE: val = t * tR; break;
+      case AGX_OUT_ENERGY: val = en * aR * aR; break;
+      case AGX_OUT_ENTHALPY: val = (en + s[4] / s[0]) * aR * aR; break;
+      case AGX_OUT_CP: val = g.cp * aR * aR / tR; break;
+      case AGX_OUT_CV: val = g.cv * aR * aR / tR; break;
+      case AGX_OUT_RANK: val = (double)sp.rank; break;
+      case AGX_OUT_GLOBAL_POSITION: val = (double)sp.global_pos; break;
+      case AGX_OUT_VISCOSITY: {
+        const double temp = t * g.t_ref;
+        val = (g.visc_c1 * temp * sqrt(temp)) / ((temp + g.visc_s) * g.mu_ref) * muR;
+        break;
+      }
+      case AGX_OUT_WALL_DISTANCE: val = b.wdist[q] * lR; break;
+#if AGX_NEQ == 7
+      case AGX_OUT_VISCOSITY_RATIO: {
+        const double temp = t * g.t_ref;
+        val = b.turb3[0][q] / ((g.visc_c1 * temp * sqrt(temp)) / ((temp + g.visc_s) * g.mu_ref));
+        break;
+      }
+      case AGX_OUT_TURB_VISCOSITY: val = b.turb3[0][q] * muR; break;
+      case AGX_OUT_TKE: val = s[5] * aR * aR; break;
+      case AGX_OUT_SDR: val = s[6] * aR * aR * rR / muR; break;
+      case AGX_OUT_F1: val = b.turb3[1][q]; break;
+      case AGX_OUT_F2: val = b.turb3[2][q]; break;
+#endif
+      default:
+        if (var >= AGX_OUT_RESID) {
+          const int e = var - AGX_OUT_RESID;
+          if (e < AGX_NEQ) {
+            const double l2 = lR * lR;
+            const double sc = e == 0 ? rR * aR * l2
+                              : e < 4 ? rR * aR * aR * l2
+                              : e < 6 ? rR * aR * aR * aR * l2
+                                      : rR * rR * aR * aR * aR * aR * l2 / muR;
+            val = b.resid[e][q] * sc;
+          }
+        } else if (var >= AGX_OUT_VELGRAD) {
+          const int gidx = var - AGX_OUT_VELGRAD;
+          const double sc = gidx < 9 ? aR / lR
+                            : gidx < 12 ? tR / lR
+                            : gidx < 15 ? rR / lR
+                            : gidx < 18 ? rR * aR * aR / lR
+                            : gidx < 21 ? aR * aR / lR
+                                        : aR * aR * rR / (muR * lR);
+          val = gidx < 3 * NGF ? grads[3 * NGF * p + gidx] * sc : 0.0;
+        }
+    }
+    out[(long)v * ncell + p] = val;
+  }
+}
+// WriteRestart (output.cpp:651-752): n_eq + 1 dimensional values per cell, cell by cell;
+// which = 0: the state, 1: consVarsNm1.  The payload is cell-major, so a wave's stores of
+// one variable are (n_eq + 1) * 8 bytes apart -- the restart interval is thousands of
+// iterations, the kernel moves 6 (8) values per cell once.
+__global__ void __launch_bounds__(256)
+k_restart_pack(BlockDev b, OutSpec sp, int which, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  const long p = ((long)k * b.nj + j) * b.ni + i;
+  const double rR = sp.rho_ref, aR = sp.a_ref, muR = sp.mu_ref;
+  const double scp[7] = {rR, aR, aR, aR, rR * aR * aR, aR * aR, aR * aR * rR / muR};
+  const double scc[7] = {rR, aR * rR, aR * rR, aR * rR, aR * aR * rR, aR * aR * rR,
+                         aR * aR * rR * rR / muR};
+  double* o = out + (AGX_NEQ + 1) * p;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e)
+    o[e] = which == 0 ? b.state[e][q] * scp[e] : b.consnm1[e][q] * scc[e];
+  o[AGX_NEQ] = 1.0;          // mass fraction of the single species
 }
 
 // Nonreflecting surfaces, after a residual: pressure and velocity gradient of the
@@ -2837,7 +2953,7 @@ __global__ void __launch_bounds__(256) k_nr_grads(BlockDev b, GasDev g) {
   if (d1 < d2) { c[d1] = lo[d1] + rem % n1; c[d2] = lo[d2] + rem / n1; }
   else { c[d2] = lo[d2] + rem % n2; c[d1] = lo[d1] + rem / n2; }
   c[d3] = st % 2 == 0 ? lo[d3] - 1 : lo[d3];
-  double acc[18];
+  double acc[3 * NGF];
   cell_grads18(b, g, b.idx(c[0], c[1], c[2]), acc);
   double* o = b.nr_grad + 12 * ((long)b.nr_off[sn] + rem);
   for (int q = 0; q < 3; ++q) o[q] = acc[15 + q];

@@ -164,6 +164,26 @@ class Solver:
                                        a.ctypes.data_as(abi.c_dp))
         self.api.check(rc, "upload")
 
+    def output_pack(self, gb, names):
+        """WriteFunFile's variables of block gb (reference names, abi.OUT), packed by the
+        library: [nvar, nk, nj, ni], dimensional."""
+        g = self.case.blocks[gb].geom
+        ni, nj, nk = g.n
+        ids = (C.c_int32 * len(names))(*[abi.OUT[n] for n in names])
+        out = np.empty((len(names), nk, nj, ni))
+        self.api.check(self.api.output_pack(self.ctx, self.block_ids[gb], len(names), ids,
+                                            out.ctypes.data_as(abi.c_dp)), "output_pack")
+        return out
+
+    def restart_pack(self, gb, which=0):
+        """WriteRestart's payload of block gb: [nk, nj, ni, n_eq + 1], dimensional."""
+        g = self.case.blocks[gb].geom
+        ni, nj, nk = g.n
+        out = np.empty((nk, nj, ni, self.cfg.n_eq + 1))
+        self.api.check(self.api.restart_pack(self.ctx, self.block_ids[gb], which,
+                                             out.ctypes.data_as(abi.c_dp)), "restart_pack")
+        return out
+
     def download(self, field, gb):
         out = np.empty(self._shape(field, gb))
         self.api.check(self.api.field_download(

@@ -89,6 +89,26 @@ enum { AGX_FIELD_STATE = 0,      /* state_      nEq, with ghosts           */
        AGX_FIELD_DENS_GRAD = 12, AGX_FIELD_PRESS_GRAD = 13
 };
 
+/* variables of a function file, WriteFunFile (output.cpp:235-407): formed and
+ * re-dimensionalised ON THE DEVICE by agx_output_pack, so an output step moves what the
+ * file holds instead of the whole state (GetFinestGridLevel, main.cpp:282).  Gradients:
+ * d/dx, d/dy, d/dz; VELGRAD in the reference's order ux vx wx uy vy wy uz vz wz
+ * (tensor XX XY XZ YX ...).  The gradients are those of the state the device holds when
+ * the call is made (the reference writes the ones its last residual accumulated,
+ * procBlock.cpp:1397-1449, i.e. of the state before the last update); eddy viscosity,
+ * f1, f2 and the residuals are the last residual's, as in the reference. */
+enum { AGX_OUT_DENSITY = 0, AGX_OUT_VEL_X, AGX_OUT_VEL_Y, AGX_OUT_VEL_Z, AGX_OUT_PRESSURE,
+       AGX_OUT_MACH, AGX_OUT_SOS, AGX_OUT_DT, AGX_OUT_TEMPERATURE, AGX_OUT_ENERGY,
+       AGX_OUT_ENTHALPY, AGX_OUT_CP, AGX_OUT_CV, AGX_OUT_RANK, AGX_OUT_GLOBAL_POSITION,
+       AGX_OUT_VISCOSITY_RATIO, AGX_OUT_TURB_VISCOSITY, AGX_OUT_VISCOSITY, AGX_OUT_TKE,
+       AGX_OUT_SDR, AGX_OUT_F1, AGX_OUT_F2, AGX_OUT_WALL_DISTANCE,
+       AGX_OUT_VELGRAD = 23,      /* .. 31: nine entries                          */
+       AGX_OUT_TEMPGRAD = 32,     /* .. 34                                        */
+       AGX_OUT_DENSGRAD = 35, AGX_OUT_PRESSGRAD = 38,
+       AGX_OUT_TKEGRAD = 41, AGX_OUT_OMEGAGRAD = 44,   /* rans library             */
+       AGX_OUT_RESID = 47,        /* .. 53: mass, mom_x, mom_y, mom_z, energy, tke, sdr */
+       AGX_OUT_COUNT = 54 };
+
 /* what a halo exchange carries (gridLevel.cpp:299-313, utility.cpp:400-423) */
 enum { AGX_HALO_STATE = 0, AGX_HALO_UPDATE = 1,
        /* velocityGrad_ of the cells across connection surfaces, swapped after the
@@ -282,6 +302,20 @@ int agx_phase_relax_forward(agx_ctx *ctx, int sweep);  /* LUSGS_Forward :341 / D
 int agx_phase_relax_backward(agx_ctx *ctx, int sweep); /* LUSGS_Backward :385 */
 int agx_phase_matrix_residual(agx_ctx *ctx, double *matrix_resid); /* linearSolver::Residual :92 */
 int agx_phase_implicit_update(agx_ctx *ctx, int mm, double *l2, agx_linf *linf); /* UpdateBlocks gridLevel.cpp:418 */
+
+/* ---- output: the payloads of the reference's files, packed on the device ----
+ * WriteFunFile (output.cpp:209-437): `nvar` variables (AGX_OUT_*, in the caller's order --
+ * the reference writes its std::set alphabetically) of one block, physical cells, i
+ * fastest, variable by variable: out[v * ni*nj*nk + cell], dimensional as the reference
+ * writes them (reference quantities from agx_config.gas).  Variables a build does not hold
+ * (tke, sdr, eddy viscosity, f1, f2 and their gradients in the 5-equation library) come
+ * out as the reference's laminar values (0), viscosity in inviscid runs is refused. */
+int agx_output_pack(agx_ctx *ctx, int block, int nvar, const int32_t *vars, double *out);
+/* WriteRestart (output.cpp:651-752), the payload of one block: cell by cell (i fastest)
+ * n_eq + 1 dimensional values -- density, velocity, pressure, [tke, sdr,] mass fraction of
+ * the single species (1).  which = 0: the state; which = 1: consVarsNm1 (the second
+ * solution of multilevel time integration: conserved variables, :700-750). */
+int agx_restart_pack(agx_ctx *ctx, int block, int which, double *out);
 
 /* halo exchange (multiArray3d.hpp:790-873 SwapSliceLocal / SwapSliceParallel).
  * local: both sides on this rank. */

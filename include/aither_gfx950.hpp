@@ -131,6 +131,20 @@ class hotPath {
     Check(AGX_SYM(field_download)(ctx_, block, field, aos), "hotPath::Download");
   }
 
+  // WriteFunFile (output.cpp:209-437): the block's payload of a function file -- the
+  // listed variables (AGX_OUT_*), physical cells, variable by variable, dimensional --
+  // formed on the device; what comes back is what the caller writes to the file
+  void OutputPack(int block, const std::vector<int32_t> &vars, double *out) const {
+    Check(AGX_SYM(output_pack)(ctx_, block, static_cast<int>(vars.size()), vars.data(), out),
+          "hotPath::OutputPack");
+  }
+  // WriteRestart (output.cpp:651-752): the block's payload, numEqns + 1 values per cell;
+  // secondSolution: consVarsNm1 (multilevel time integration)
+  void RestartPack(int block, bool secondSolution, double *out) const {
+    Check(AGX_SYM(restart_pack)(ctx_, block, secondSolution ? 1 : 0, out),
+          "hotPath::RestartPack");
+  }
+
   // mgSolution::StoreOldSolution: consVarsN <- cons(state) (and N-1 on the first
   // step of a multilevel-in-time scheme)
   void StoreOldSolution(bool alsoNm1) {

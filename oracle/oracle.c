@@ -1691,10 +1691,12 @@ static double grad_field(const ora_ctx *c, const blk_t *b, long cell, int f) {
   const double *s = b->state + NEQ * cell;
   if (f < 3) return s[1 + f];
   if (f == 3) return temperature(c, s);
+  if (f >= 6) return s[f - 1];               /* rans: k (6), omega (7) */
   return f == 4 ? s[0] : s[4];
 }
-static void face_grad6(const ora_ctx *c, const blk_t *b, int d, int i, int j, int k,
-                       double g6[3][6]) {
+#define NGF_MAX 8   /* u, v, w, T, rho, p [, k, omega] */
+static void face_gradn(const ora_ctx *c, const blk_t *b, int d, int i, int j, int k,
+                       int nf, double g6[3][NGF_MAX]) {
   static const int o[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   const int *od = o[d];
   double au[3][3], al[3][3];
@@ -1719,7 +1721,7 @@ static void face_grad6(const ora_ctx *c, const blk_t *b, int d, int i, int j, in
   const long cL = CI(b, i - od[0], j - od[1], k - od[2]);
   const long cU = CI(b, i, j, k);
   const double invVol = 1.0 / (0.5 * (b->vol[cL] + b->vol[cU]));
-  for (int f = 0; f < 6; ++f) {
+  for (int f = 0; f < nf; ++f) {
     double vl[3], vu[3];
     const double fL = grad_field(c, b, cL, f), fU = grad_field(c, b, cU, f);
     vl[d] = fL;
@@ -1739,26 +1741,29 @@ static void face_grad6(const ora_ctx *c, const blk_t *b, int d, int i, int j, in
                   vu[2] * au[2][r] - vl[2] * al[2][r]) * invVol;
   }
 }
-static void cell_gradients(const ora_ctx *c, const blk_t *b, double *out) {
+/* out: [cell][3 nf]; per field f >= 3 the three derivatives at 9 + 3 (f - 3) */
+static void cell_gradients_n(const ora_ctx *c, const blk_t *b, int nf, double *out) {
   const double sixth = 1.0 / 6.0;
+  const int ng3 = 3 * nf;
   for (int k = 0; k < b->nk; ++k)
     for (int j = 0; j < b->nj; ++j)
       for (int i = 0; i < b->ni; ++i) {
-        double acc[18];
-        for (int q = 0; q < 18; ++q) acc[q] = 0.0;
+        double acc[3 * NGF_MAX];
+        for (int q = 0; q < ng3; ++q) acc[q] = 0.0;
         for (int d = 0; d < 3; ++d)
           for (int up = 0; up < 2; ++up) {
-            double g6[3][6];
-            face_grad6(c, b, d, i + (up && d == 0), j + (up && d == 1), k + (up && d == 2), g6);
+            double g6[3][NGF_MAX];
+            face_gradn(c, b, d, i + (up && d == 0), j + (up && d == 1), k + (up && d == 2), nf, g6);
             for (int r = 0; r < 3; ++r) {
               for (int f = 0; f < 3; ++f) acc[3 * r + f] += sixth * g6[r][f];
-              acc[9 + r] += sixth * g6[r][3];
-              acc[12 + r] += sixth * g6[r][4];
-              acc[15 + r] += sixth * g6[r][5];
+              for (int f = 3; f < nf; ++f) acc[9 + 3 * (f - 3) + r] += sixth * g6[r][f];
             }
           }
-        memcpy(out + 18 * PI(b, i, j, k), acc, sizeof acc);
+        memcpy(out + ng3 * PI(b, i, j, k), acc, sizeof(double) * ng3);
       }
+}
+static void cell_gradients(const ora_ctx *c, const blk_t *b, double *out) {
+  cell_gradients_n(c, b, 6, out);
 }
 
 /* FaceReconCentral reconstruction.hpp:315-328 with LagrangeCoeff(.,1,0,0) */
@@ -2859,6 +2864,107 @@ int ora_field_download(ora_ctx *c, int id, int field, double *out) {
   double *p = field_ptr(&c->blk[id], field, &n);
   if (!p) return fail("unknown field %d", field);
   memcpy(out, p, sizeof(double) * n);
+  return 0;
+}
+/* WriteFunFile output.cpp:209-437: variables of one block, variable by variable, physical
+ * cells, dimensional (the scales of :235-407) */
+int ora_output_pack(ora_ctx *c, int id, int nvar, const int32_t *vars, double *out) {
+  if (id < 0 || id >= c->nblk) return fail("bad block id");
+  blk_t *b = &c->blk[id];
+  const agx_gas *gs = &c->cfg.gas;
+  const double rR = gs->rho_ref, aR = gs->a_ref, lR = gs->l_ref, tR = gs->t_ref, muR = c->mu_ref;
+  const int nf = 6 + (NEQ - NF);
+  double *gr = NULL;
+  for (int v = 0; v < nvar; ++v) {
+    if (vars[v] < 0 || vars[v] >= AGX_OUT_COUNT) return fail("unknown output variable %d", vars[v]);
+    if (vars[v] == AGX_OUT_VISCOSITY && !c->cfg.is_viscous)
+      return fail("viscosity_ is only kept for viscous runs (procBlock.cpp:6171)");
+    if (vars[v] >= AGX_OUT_VELGRAD && vars[v] < AGX_OUT_RESID && !gr) {
+      gr = (double *)malloc(sizeof(double) * 3 * nf * b->ncell);
+      cell_gradients_n(c, b, nf, gr);
+    }
+  }
+  for (int v = 0; v < nvar; ++v) {
+    const int var = vars[v];
+    double *o = out + (long)v * b->ncell;
+    for (int k = 0; k < b->nk; ++k)
+      for (int j = 0; j < b->nj; ++j)
+        for (int i = 0; i < b->ni; ++i) {
+          const long p = PI(b, i, j, k), q = CI(b, i, j, k);
+          const double *s = b->state + NEQ * q;
+          const double t = temperature(c, s);
+          const double vmag = sqrt(dot3(s + 1, s + 1));
+          double val = 0.0;
+          switch (var) {
+            case AGX_OUT_DENSITY: val = s[0] * rR; break;
+            case AGX_OUT_VEL_X: val = s[1] * aR; break;
+            case AGX_OUT_VEL_Y: val = s[2] * aR; break;
+            case AGX_OUT_VEL_Z: val = s[3] * aR; break;
+            case AGX_OUT_PRESSURE: val = s[4] * rR * aR * aR; break;
+            case AGX_OUT_MACH: val = vmag / sos(c, s); break;
+            case AGX_OUT_SOS: val = sos(c, s) * aR; break;
+            case AGX_OUT_DT: val = b->dt[p] / (aR * lR); break;
+            case AGX_OUT_TEMPERATURE: val = t * tR; break;
+            case AGX_OUT_ENERGY: val = energy(c, s) * aR * aR; break;
+            case AGX_OUT_ENTHALPY: val = enthalpy(c, s) * aR * aR; break;
+            case AGX_OUT_CP: val = gs->gas_constant * (gs->n + 1.0) * aR * aR / tR; break;
+            case AGX_OUT_CV: val = gs->gas_constant * gs->n * aR * aR / tR; break;
+            case AGX_OUT_RANK: val = (double)c->rank; break;
+            case AGX_OUT_GLOBAL_POSITION: val = (double)b->gpos; break;
+            case AGX_OUT_VISCOSITY_RATIO:
+              val = NEQ > NF ? b->turb3[3 * q] / viscosity(c, t) : 0.0; break;
+            case AGX_OUT_TURB_VISCOSITY: val = NEQ > NF ? b->turb3[3 * q] * muR : 0.0; break;
+            case AGX_OUT_VISCOSITY: val = viscosity(c, t) * muR; break;
+            case AGX_OUT_TKE: val = NEQ > NF ? s[5] * aR * aR : 0.0; break;
+            case AGX_OUT_SDR: val = NEQ > NF ? s[6] * aR * aR * rR / muR : 0.0; break;
+            case AGX_OUT_F1: val = NEQ > NF ? b->turb3[3 * q + 1] : 0.0; break;
+            case AGX_OUT_F2: val = NEQ > NF ? b->turb3[3 * q + 2] : 0.0; break;
+            case AGX_OUT_WALL_DISTANCE: val = (b->wdist ? b->wdist[q] : 0.0) * lR; break;
+            default:
+              if (var >= AGX_OUT_RESID) {
+                const int e = var - AGX_OUT_RESID;
+                const double sc[7] = {rR * aR * lR * lR, rR * aR * aR * lR * lR,
+                                      rR * aR * aR * lR * lR, rR * aR * aR * lR * lR,
+                                      rR * pow(aR, 3.0) * lR * lR, rR * pow(aR, 3.0) * lR * lR,
+                                      rR * rR * pow(aR, 4.0) * lR * lR / muR};
+                val = e < NEQ ? b->resid[NEQ * p + e] * sc[e] : 0.0;
+              } else {
+                const int gidx = var - AGX_OUT_VELGRAD;      /* 0 .. 23 */
+                const double sc = gidx < 9 ? aR / lR
+                                  : gidx < 12 ? tR / lR
+                                  : gidx < 15 ? rR / lR
+                                  : gidx < 18 ? rR * aR * aR / lR
+                                  : gidx < 21 ? aR * aR / lR
+                                              : aR * aR * rR / (muR * lR);
+                val = gidx < 3 * nf ? gr[3 * nf * p + gidx] * sc : 0.0;
+              }
+          }
+          o[p] = val;
+        }
+  }
+  free(gr);
+  return 0;
+}
+/* WriteRestart output.cpp:651-752, the payload of one block */
+int ora_restart_pack(ora_ctx *c, int id, int which, double *out) {
+  if (id < 0 || id >= c->nblk) return fail("bad block id");
+  if (which != 0 && which != 1) return fail("which is 0 (state) or 1 (consVarsNm1)");
+  blk_t *b = &c->blk[id];
+  const agx_gas *gs = &c->cfg.gas;
+  const double rR = gs->rho_ref, aR = gs->a_ref, muR = c->mu_ref;
+  const double sp[7] = {rR, aR, aR, aR, rR * aR * aR, aR * aR, aR * aR * rR / muR};
+  const double sc[7] = {rR, aR * rR, aR * rR, aR * rR, aR * aR * rR, aR * aR * rR,
+                        aR * aR * rR * rR / muR};
+  const int nv = NEQ + 1;
+  for (int k = 0; k < b->nk; ++k)
+    for (int j = 0; j < b->nj; ++j)
+      for (int i = 0; i < b->ni; ++i) {
+        const long p = PI(b, i, j, k), q = CI(b, i, j, k);
+        double *o = out + nv * p;
+        for (int e = 0; e < NEQ; ++e)
+          o[e] = which == 0 ? b->state[NEQ * q + e] * sp[e] : b->consnm1[NEQ * p + e] * sc[e];
+        o[NEQ] = 1.0;        /* mass fraction of the single species */
+      }
   return 0;
 }
 int ora_field_upload(ora_ctx *c, int id, int field, const double *in) {

@@ -35,6 +35,8 @@ int ora_setup_finalize(ora_ctx *ctx);
 int ora_state_upload(ora_ctx *ctx, int block_id, const double *state_aos);
 int ora_field_download(ora_ctx *ctx, int block_id, int field, double *out);
 int ora_field_upload(ora_ctx *ctx, int block_id, int field, const double *in);
+int ora_output_pack(ora_ctx *ctx, int block_id, int nvar, const int32_t *vars, double *out);
+int ora_restart_pack(ora_ctx *ctx, int block_id, int which, double *out);
 int ora_store_time_n(ora_ctx *ctx, int also_nm1);
 int ora_iterate(ora_ctx *ctx, int mm, double cfl, double *l2, agx_linf *linf,
                 double *matrix_resid);
