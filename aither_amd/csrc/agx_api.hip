@@ -931,7 +931,7 @@ int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
                           c->stream));
   HIPCHK(hipMemcpyAsync(c->err_host, c->err_dev, sizeof(int),
                         hipMemcpyDeviceToHost, c->stream));
-  if (c->in_iterate && mode != 2 && c->eager_ghosts) {
+  if (c->in_iterate && c->eager_ghosts) {
     // the host waits for the norms only; the ghost fill of the next iteration is
     // already queued behind them
     if (!c->norm_event) HIPCHK(hipEventCreateWithFlags(&c->norm_event, hipEventDisableTiming));
@@ -1529,6 +1529,25 @@ static int d2_x_copy(agx_ctx* c, Block& b, int to_d2) {
   return 0;
 }
 
+// The gradients an output step asks for reach into the ghost cells: they are formed with
+// the ghost cells the NEXT residual would see -- the inviscid fill of the state as it is now
+// (already queued behind the last update unless something touched the state since), then
+// the viscous-wall fill (gridLevel.cpp:287-319, procBlock.cpp:6131-6136).  Ghost cells of
+// connections to other ranks stay as last exchanged (an output step is not a collective).
+static int ghosts_for_output(agx_ctx* c) {
+  if (!c->ghosts_prefilled) {
+    if (agx_phase_bc_faces(c)) return 1;
+    if (agx_halo_swap_local(c, AGX_HALO_STATE)) return 1;
+    if (agx_phase_bc_edges(c)) return 1;
+  }
+  if (c->cfg.is_viscous) {
+    if (bc_pass(c, true, 1)) return 1;
+    if (bc_pass(c, false, 1)) return 1;
+  }
+  c->ghosts_prefilled = false;   // (the next iteration starts from its own inviscid fill)
+  return 0;
+}
+
 int agx_field_download(agx_ctx* c, int id, int field, double* out) {
   if (flush_consn(c)) return 1;
   if (id < 0 || id >= (int)c->blocks.size()) return fail("bad block id %d", id);
@@ -1538,6 +1557,7 @@ int agx_field_download(agx_ctx* c, int id, int field, double* out) {
     // cell-centre gradients: formed on demand into a temporary (an output path)
     const long ncell = (long)b.d.ni * b.d.nj * b.d.nk;
     double* tmp = nullptr;
+    if (ghosts_for_output(c)) return 1;
     if (stage_buffer(c, (size_t)3 * NGF * ncell, &tmp)) return 1;
     hipLaunchKernelGGL(k_cell_grads, cell_grid(b.d, CELL_BLOCK), CELL_BLOCK, 0, c->stream, b.d,
                        c->gas, tmp);
@@ -1602,9 +1622,11 @@ int agx_output_pack(agx_ctx* c, int id, int nvar, const int32_t* vars, double* o
   double* tmp = nullptr;
   const size_t gdoubles = need_grads ? (size_t)3 * NGF * ncell : 0;
   if (stage_buffer(c, gdoubles + (size_t)nvar * ncell, &tmp)) return 1;
-  if (need_grads)
+  if (need_grads) {
+    if (ghosts_for_output(c)) return 1;
     hipLaunchKernelGGL(k_cell_grads, cell_grid(b.d, CELL_BLOCK), CELL_BLOCK, 0, c->stream, b.d,
                        c->gas, tmp);
+  }
   double* packed = tmp + gdoubles;
   hipLaunchKernelGGL(k_output_pack, cell_grid(b.d, CELL_BLOCK), CELL_BLOCK, 0, c->stream, b.d,
                      c->gas, sp, need_grads ? tmp : nullptr, packed);
@@ -1649,6 +1671,10 @@ int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
 int agx_store_time_n(agx_ctx* c, int also_nm1) {
   if (flush_consn(c)) return 1;
   c->have_time_n = true;
+  // nonreflecting ghost states read consVarsN (ghostStates.cpp:435-462): a ghost fill
+  // queued behind the last update saw the old time level
+  for (auto& blk : c->blocks)
+    if (blk.nr_max > 0) c->ghosts_prefilled = false;
   // Explicit fused path: the stage-0 launch of k_residual_tile forms
   // cons(state) anyway and writes it to consVarsN itself (5 stores instead of a
   // separate 5-load/5-store pass); anything else that touches consVarsN or the
@@ -2166,8 +2192,8 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
   }
 #undef AGX_PHASE
 #undef AGX_XCHG
-  // the explicit update queues the next call's ghost fill -- an exchange -- behind its norms
-  if (st && collective && !c->sp.implicit && c->eager_ghosts) (void)fill_ghosts(c);
+  // the update queues the next call's ghost fill -- an exchange -- behind its norms
+  if (st && collective && c->eager_ghosts) (void)fill_ghosts(c);
   if (st) memcpy(g_err, first_err, sizeof g_err);
   if (c->have_ex) return reduce_over_ranks(c, l2, linf, matrix_resid, l2_in, st);
   return st;

@@ -83,7 +83,10 @@ enum { AGX_FIELD_STATE = 0,      /* state_      nEq, with ghosts           */
        /* cell-centre gradients (velocityGrad_, temperatureGrad_, densityGrad_,
         * pressureGrad_; procBlock.cpp:1397-1449, :5950-5954): the mean of the six
         * Green-Gauss face gradients of the cell, formed ON DEMAND from the state
-        * the device holds (they are not kept between iterations); no ghosts.
+        * the device holds (they are not kept between iterations) with the ghost
+        * cells the next residual would see: the inviscid fill of that state, then
+        * the viscous-wall fill (ghost cells of connections to other ranks as last
+        * exchanged); no ghosts.
         * VEL_GRAD: 9 per cell, [3 r + c] = d(velocity c)/d(x_r) (tensor.hpp) */
        AGX_FIELD_VEL_GRAD = 10, AGX_FIELD_TEMP_GRAD = 11,
        AGX_FIELD_DENS_GRAD = 12, AGX_FIELD_PRESS_GRAD = 13
@@ -94,9 +97,10 @@ enum { AGX_FIELD_STATE = 0,      /* state_      nEq, with ghosts           */
  * file holds instead of the whole state (GetFinestGridLevel, main.cpp:282).  Gradients:
  * d/dx, d/dy, d/dz; VELGRAD in the reference's order ux vx wx uy vy wy uz vz wz
  * (tensor XX XY XZ YX ...).  The gradients are those of the state the device holds when
- * the call is made (the reference writes the ones its last residual accumulated,
- * procBlock.cpp:1397-1449, i.e. of the state before the last update); eddy viscosity,
- * f1, f2 and the residuals are the last residual's, as in the reference. */
+ * the call is made, with the ghost cells the next residual would see (AGX_FIELD_VEL_GRAD;
+ * the reference writes the ones its last residual accumulated, procBlock.cpp:1397-1449,
+ * i.e. of the state before the last update); eddy viscosity, f1, f2 and the residuals
+ * are the last residual's, as in the reference. */
 enum { AGX_OUT_DENSITY = 0, AGX_OUT_VEL_X, AGX_OUT_VEL_Y, AGX_OUT_VEL_Z, AGX_OUT_PRESSURE,
        AGX_OUT_MACH, AGX_OUT_SOS, AGX_OUT_DT, AGX_OUT_TEMPERATURE, AGX_OUT_ENERGY,
        AGX_OUT_ENTHALPY, AGX_OUT_CP, AGX_OUT_CV, AGX_OUT_RANK, AGX_OUT_GLOBAL_POSITION,

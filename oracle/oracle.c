@@ -2848,10 +2848,29 @@ static double *field_ptr(blk_t *b, int field, long *n) {
   }
   return NULL;
 }
+/* The gradients an output step asks for reach into the ghost cells: they are formed with
+ * the ghost cells the NEXT residual would see -- the inviscid fill of the state as it is
+ * now, then the viscous-wall fill (gridLevel.cpp:287-319, procBlock.cpp:6131-6136); ghost
+ * cells of connections to other ranks stay as last exchanged. */
+int ora_phase_bc_faces(ora_ctx *c);
+int ora_phase_bc_edges(ora_ctx *c);
+int ora_halo_swap_local(ora_ctx *c, int what);
+static int ghosts_for_output(ora_ctx *c) {
+  if (ora_phase_bc_faces(c)) return 1;
+  if (ora_halo_swap_local(c, AGX_HALO_STATE)) return 1;
+  if (ora_phase_bc_edges(c)) return 1;
+  if (c->cfg.is_viscous)
+    for (int n = 0; n < c->nblk; ++n) {
+      if (assign_ghost_faces(c, &c->blk[n], 1)) return 1;
+      if (assign_ghost_edges(c, &c->blk[n], 1)) return 1;
+    }
+  return 0;
+}
 int ora_field_download(ora_ctx *c, int id, int field, double *out) {
   if (id < 0 || id >= c->nblk) return fail("bad block id");
   if (field >= AGX_FIELD_VEL_GRAD && field <= AGX_FIELD_PRESS_GRAD) {
     blk_t *b = &c->blk[id];
+    if (ghosts_for_output(c)) return 1;
     double *all = (double *)malloc(sizeof(double) * 18 * b->ncell);
     cell_gradients(c, b, all);
     const int off = field == AGX_FIELD_VEL_GRAD ? 0 : 9 + 3 * (field - AGX_FIELD_TEMP_GRAD);
@@ -2880,6 +2899,7 @@ int ora_output_pack(ora_ctx *c, int id, int nvar, const int32_t *vars, double *o
     if (vars[v] == AGX_OUT_VISCOSITY && !c->cfg.is_viscous)
       return fail("viscosity_ is only kept for viscous runs (procBlock.cpp:6171)");
     if (vars[v] >= AGX_OUT_VELGRAD && vars[v] < AGX_OUT_RESID && !gr) {
+      if (ghosts_for_output(c)) return 1;
       gr = (double *)malloc(sizeof(double) * 3 * nf * b->ncell);
       cell_gradients_n(c, b, nf, gr);
     }
