@@ -135,6 +135,8 @@ SYMBOLS = {
     "field_upload": (_i, [_vp, _i, _i, c_dp]),
     "output_pack": (_i, [_vp, _i, _i, C.POINTER(C.c_int32), c_dp]),
     "restart_pack": (_i, [_vp, _i, _i, c_dp]),
+    "plot3d_metrics": (_i, [_vp, _i, _i, _i] + [c_dp] * 9),
+    "nearest_wall_distance": (_i, [_vp, C.c_int64, c_dp, C.c_int64, c_dp, c_dp]),
     "store_time_n": (_i, [_vp, _i]),
     "iterate": (_i, [_vp, _i, C.c_double, c_dp, C.POINTER(Linf), c_dp]),
     "phase_bc_faces": (_i, [_vp]),

@@ -158,10 +158,11 @@ def farfield_turbulence(gas, prim, vel, intensity, ratio):
     return max(tke, TURB_MIN), max(omega, TURB_MIN)
 
 
-def _wall_distance(blocks):
+def _wall_distance(blocks, nearest=None):
     """main.cpp:191-203: nearest viscous-wall face centre (k-d tree), then the
-    ghost-cell rule of procBlock::CalcWallDistance (procBlock.cpp:6030-6107)."""
-    from scipy.spatial import cKDTree
+    ghost-cell rule of procBlock::CalcWallDistance (procBlock.cpp:6030-6107).
+    nearest(cell_centres, wall_points) -> distances: the library's
+    agx_nearest_wall_distance (solver.DeviceSetup); default: scipy's k-d tree."""
     pts = []
     for b in blocks:
         g = b.geom
@@ -173,12 +174,16 @@ def _wall_distance(blocks):
             pts.append(g.fcen[f].v(rng["i"], rng["j"], rng["k"]).reshape(-1, 3))
     if not pts:
         return
-    tree = cKDTree(np.concatenate(pts))
+    walls = np.ascontiguousarray(np.concatenate(pts))
+    if nearest is None:
+        from scipy.spatial import cKDTree
+        tree = cKDTree(walls)
+        nearest = lambda cen, _w: tree.query(cen)[0]
     for b in blocks:
         g = b.geom
         ni, nj, nk, ng = g.ni, g.nj, g.nk, g.ng
-        cen = g.center.phys().reshape(-1, 3)
-        dist, _ = tree.query(cen)
+        cen = np.ascontiguousarray(g.center.phys().reshape(-1, 3))
+        dist = nearest(cen, walls)
         wd = g.wall_dist
         wd.phys()[..., 0] = dist.reshape(nk, nj, ni)
         n = {"i": ni, "j": nj, "k": nk}
@@ -202,9 +207,10 @@ def _wall_distance(blocks):
                     sign * wd.v(rs["i"], rs["j"], rs["k"])
 
 
-def build_case(inp_path, grid_dir=None, deck=None, coords=None, ranks=None):
+def build_case(inp_path, grid_dir=None, deck=None, coords=None, ranks=None, setup=None):
     """Build a Case from an .inp file (and its .xyz grid).  `deck`/`coords`
-    may be given directly for synthetic cases."""
+    may be given directly for synthetic cases.  setup: a solver.DeviceSetup -- the
+    volume-sized parts (metrics, wall distance) then run in the library."""
     if deck is None:
         deck = parse_input(inp_path)
     deck.validate()
@@ -227,7 +233,7 @@ def build_case(inp_path, grid_dir=None, deck=None, coords=None, ranks=None):
     blocks = []
     total = 0
     for b, x in enumerate(coords):
-        g = _geo.BlockGeometry(x, ng)
+        g = _geo.BlockGeometry(x, ng, metrics=setup.metrics if setup else None)
         g.assign_ghost_geom(deck.bcs[b])
         ic_file = deck.ic_for_block(b).get("file")
         if ic_file is not None:       # (relative to the case directory, as the reference runs)
@@ -248,7 +254,7 @@ def build_case(inp_path, grid_dir=None, deck=None, coords=None, ranks=None):
         b.geom.assign_ghost_geom_edge()
         b.geom.calc_cell_widths()
     if deck.is_viscous():
-        _wall_distance(blocks)
+        _wall_distance(blocks, setup.nearest if setup else None)
         # SwapWallDist (gridLevel.cpp:261-285)
         for c in conns:
             _swap_cell_field(c, blocks, lambda blk: blk.geom.wall_dist.a, ng)

@@ -204,11 +204,13 @@ def _grow(arr, d):
 class BlockGeometry:
     """Ghost-padded metrics of one block."""
 
-    def __init__(self, coords, ng):
+    def __init__(self, coords, ng, metrics=None):
+        """metrics: a function nodes -> the dict interior_metrics returns (the library's
+        agx_plot3d_metrics through solver.DeviceSetup); default: the numpy form here."""
         nk, nj, ni = (s - 1 for s in coords.shape[:3])
         self.ni, self.nj, self.nk, self.ng = ni, nj, nk, ng
         self.nodes = coords
-        m = interior_metrics(coords)
+        m = (metrics or interior_metrics)(coords)
         self.vol = _pad(m["vol"], ng)
         self.center = _pad(m["center"], ng)
         self.farea = {d: _pad(m["farea_" + d], ng) for d in "ijk"}

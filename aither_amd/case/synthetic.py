@@ -125,19 +125,19 @@ def box_surfaces(ni, nj, nk, bcs=None):
 
 
 def single_block_case(n=(16, 16, 16), stretch=1.0, skew=0.0, bcs=None,
-                      amplitude=0.05, **deck_kw):
+                      amplitude=0.05, setup=None, **deck_kw):
     ni, nj, nk = n
     deck = make_deck(**deck_kw)
     deck.bcs = [box_surfaces(ni, nj, nk, bcs)]
     coords = [box_nodes(ni, nj, nk, stretch, skew=skew)]
-    case = _b.build_case(None, deck=deck, coords=coords)
+    case = _b.build_case(None, deck=deck, coords=coords, setup=setup)
     if amplitude:
         perturbed_state(case, amplitude)
     return case
 
 
 def stacked_blocks_case(n=(16, 16, 16), nblocks=2, axis="k", stretch=1.0,
-                        bcs=None, amplitude=0.05, ranks=None, **deck_kw):
+                        bcs=None, amplitude=0.05, ranks=None, setup=None, **deck_kw):
     """nblocks boxes stacked along `axis`, joined by interblock connections
     (orientation 1, lower <-> upper)."""
     ni, nj, nk = n
@@ -166,14 +166,14 @@ def stacked_blocks_case(n=(16, 16, 16), nblocks=2, axis="k", stretch=1.0,
             blk_bcs[hi_s] = ("interblock", 1000 * lo_s + (b + 1))
         all_bcs.append(box_surfaces(ni, nj, nk, blk_bcs))
     deck.bcs = all_bcs
-    case = _b.build_case(None, deck=deck, coords=coords, ranks=ranks)
+    case = _b.build_case(None, deck=deck, coords=coords, ranks=ranks, setup=setup)
     if amplitude:
         perturbed_state(case, amplitude)
     return case
 
 
 def cube_blocks_case(n=(8, 8, 8), splits=(2, 2, 2), bcs=None, amplitude=0.05,
-                     ranks=None, **deck_kw):
+                     ranks=None, setup=None, **deck_kw):
     """splits[0] x splits[1] x splits[2] boxes of n cells each tiling one box
     (BASELINE configs[3] style: 2x2x2 = 8 blocks), joined face to face by
     interblock connections; block id = bi + si * (bj + sj * bk)."""
@@ -199,7 +199,7 @@ def cube_blocks_case(n=(8, 8, 8), splits=(2, 2, 2), bcs=None, amplitude=0.05,
                         blk[hi_s] = ("interblock", 1000 * lo_s + bid(*nb))
                 all_bcs.append(box_surfaces(ni, nj, nk, blk))
     deck.bcs = all_bcs
-    case = _b.build_case(None, deck=deck, coords=coords, ranks=ranks)
+    case = _b.build_case(None, deck=deck, coords=coords, ranks=ranks, setup=setup)
     if amplitude:
         perturbed_state(case, amplitude)
     return case

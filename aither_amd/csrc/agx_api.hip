@@ -1654,6 +1654,64 @@ int agx_restart_pack(agx_ctx* c, int id, int which, double* out) {
   return 0;
 }
 
+// ---- set-up helpers -------------------------------------------------
+int agx_plot3d_metrics(agx_ctx* c, int ni, int nj, int nk, const double* nodes, double* vol,
+                       double* center, double* fai, double* faj, double* fak, double* fci,
+                       double* fcj, double* fck) {
+  if (ni < 1 || nj < 1 || nk < 1) return fail("empty block");
+  HIPCHK(hipSetDevice(c->device));
+  const long nn = (long)(ni + 1) * (nj + 1) * (nk + 1), ncell = (long)ni * nj * nk;
+  const long nf[3] = {(long)(ni + 1) * nj * nk, (long)ni * (nj + 1) * nk, (long)ni * nj * (nk + 1)};
+  double* host_out[8] = {vol, center, fai, faj, fak, fci, fcj, fck};
+  const long count[8] = {ncell, 3 * ncell, 4 * nf[0], 4 * nf[1], 4 * nf[2], 3 * nf[0], 3 * nf[1],
+                         3 * nf[2]};
+  size_t total = (size_t)3 * nn;
+  for (int q = 0; q < 8; ++q) if (host_out[q]) total += (size_t)count[q];
+  double* buf = nullptr;
+  if (stage_buffer(c, total, &buf)) return 1;
+  HIPCHK(hipMemcpyAsync(buf, nodes, sizeof(double) * 3 * nn, hipMemcpyHostToDevice, c->stream));
+  double* dev_out[8];
+  double* cur = buf + 3 * nn;
+  for (int q = 0; q < 8; ++q) { dev_out[q] = host_out[q] ? cur : nullptr; if (host_out[q]) cur += count[q]; }
+  MetricsOut o;
+  o.vol = dev_out[0]; o.center = dev_out[1];
+  for (int d = 0; d < 3; ++d) { o.fa[d] = dev_out[2 + d]; o.fc[d] = dev_out[5 + d]; }
+  HIPCHK(hipMemsetAsync(c->err_dev, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_plot3d_metrics, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream,
+                     ni, nj, nk, buf, o, c->err_dev);
+  HIPCHK(hipGetLastError());
+  for (int q = 0; q < 8; ++q)
+    if (host_out[q])
+      HIPCHK(hipMemcpyAsync(host_out[q], dev_out[q], sizeof(double) * count[q],
+                            hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->err_host, c->err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (*c->err_host == 4) {
+    *c->err_host = 0;
+    hipMemsetAsync(c->err_dev, 0, sizeof(int), c->stream);
+    return fail("negative volume in PLOT3D block");
+  }
+  return 0;
+}
+
+int agx_nearest_wall_distance(agx_ctx* c, int64_t ncell, const double* cen, int64_t nwall,
+                              const double* wall, double* dist) {
+  if (ncell < 1) return 0;
+  if (nwall < 1) return fail("no wall points");
+  HIPCHK(hipSetDevice(c->device));
+  double* buf = nullptr;
+  if (stage_buffer(c, (size_t)(4 * ncell + 3 * nwall), &buf)) return 1;
+  double *dc = buf, *dw = buf + 3 * ncell, *dd = dw + 3 * nwall;
+  HIPCHK(hipMemcpyAsync(dc, cen, sizeof(double) * 3 * ncell, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dw, wall, sizeof(double) * 3 * nwall, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_nearest_wall, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream,
+                     (long)ncell, dc, (long)nwall, dw, dd);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(dist, dd, sizeof(double) * ncell, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
   c->ghosts_prefilled = false;
   c->state_is_time_n = false;

@@ -2976,6 +2976,126 @@ __global__ void __launch_bounds__(256) k_aux_field(BlockDev b, GasDev g, int whi
 }
 
 // ---------------------------------------------------------------------------
+// Set-up.  plot3dBlock::Volume / Centroid / FaceAreaI,J,K / FaceCenterI,J,K
+// (plot3d.cpp:35-360) from the node coordinates x[nk+1][nj+1][ni+1][3]: one thread per
+// node, which forms the cell and the three faces that have this node as their lowest
+// corner.  Outputs in the reference's layout (agx_plot3d_metrics); null = not wanted.
+struct MetricsOut { double *vol, *center, *fa[3], *fc[3]; };
+__device__ __forceinline__ void m_sub(const double* a, const double* b, double* o) {
+  o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2];
+}
+__device__ __forceinline__ void m_cross(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];                 // vector3d::CrossProd vector3d.hpp:330-339
+  o[1] = -1.0 * (a[0] * b[2] - a[2] * b[0]);
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ double m_pyramid(const double* p, const double* a, const double* b,
+                                            const double* c, const double* d) {
+  double xp[3], xac[3], xbd[3], cr[3];            // PyramidVolume plot3d.cpp:490-498
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    xp[q] = 0.25 * ((((a[q] - p[q]) + (b[q] - p[q])) + (c[q] - p[q])) + (d[q] - p[q]));
+  m_sub(c, a, xac);
+  m_sub(d, b, xbd);
+  m_cross(xac, xbd, cr);
+  return 1.0 / 6.0 * dot3(xp, cr);
+}
+__device__ __forceinline__ void m_face(const double* n00, const double* n10, const double* n01,
+                                       const double* n11, const double* xac, const double* xbd,
+                                       double* fa, double* fc) {
+  double cr[3];
+  m_cross(xbd, xac, cr);
+  const double h[3] = {0.5 * cr[0], 0.5 * cr[1], 0.5 * cr[2]};
+  const double mag = sqrt(dot3(h, h));
+  if (fa) { fa[0] = h[0] / mag; fa[1] = h[1] / mag; fa[2] = h[2] / mag; fa[3] = mag; }
+  if (fc) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fc[q] = 0.25 * (((n00[q] + n10[q]) + n01[q]) + n11[q]);
+  }
+}
+__global__ void __launch_bounds__(256)
+k_plot3d_metrics(int ni, int nj, int nk, const double* __restrict__ x, MetricsOut o, int* err) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nn = (long)(ni + 1) * (nj + 1) * (nk + 1);
+  if (t >= nn) return;
+  const int i = (int)(t % (ni + 1)), j = (int)((t / (ni + 1)) % (nj + 1)),
+            k = (int)(t / ((long)(ni + 1) * (nj + 1)));
+  auto nd = [&](int a, int b, int c, double* v) {
+    const double* p = x + 3 * (((long)c * (nj + 1) + b) * (ni + 1) + a);
+    v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+  };
+  if (i < ni && j < nj && k < nk && (o.vol || o.center)) {
+    double c000[3], c100[3], c010[3], c110[3], c001[3], c101[3], c011[3], c111[3], cen[3];
+    nd(i, j, k, c000); nd(i + 1, j, k, c100); nd(i, j + 1, k, c010); nd(i + 1, j + 1, k, c110);
+    nd(i, j, k + 1, c001); nd(i + 1, j, k + 1, c101); nd(i, j + 1, k + 1, c011);
+    nd(i + 1, j + 1, k + 1, c111);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      cen[q] = 0.125 * (((((((c000[q] + c100[q]) + c010[q]) + c110[q]) + c001[q]) + c101[q]) +
+                         c011[q]) + c111[q]);
+    const long p = ((long)k * nj + j) * ni + i;
+    if (o.center) { o.center[3 * p] = cen[0]; o.center[3 * p + 1] = cen[1]; o.center[3 * p + 2] = cen[2]; }
+    if (o.vol) {
+      double v = m_pyramid(cen, c000, c001, c011, c010);
+      v = v + m_pyramid(cen, c100, c110, c111, c101);
+      v = v + m_pyramid(cen, c000, c100, c101, c001);
+      v = v + m_pyramid(cen, c010, c011, c111, c110);
+      v = v + m_pyramid(cen, c000, c010, c110, c100);
+      v = v + m_pyramid(cen, c001, c101, c111, c011);
+      if (!(v > 0.0)) *err = 4;          // "negative volume in PLOT3D block"
+      o.vol[p] = v;
+    }
+  }
+  double n00[3], n10[3], n01[3], n11[3], xac[3], xbd[3];
+  if (j < nj && k < nk && (o.fa[0] || o.fc[0])) {          // i-face, plot3d.cpp:150-181
+    nd(i, j, k, n00); nd(i, j + 1, k, n10); nd(i, j, k + 1, n01); nd(i, j + 1, k + 1, n11);
+    m_sub(n11, n00, xac); m_sub(n10, n01, xbd);
+    const long f = ((long)k * nj + j) * (ni + 1) + i;
+    m_face(n00, n10, n01, n11, xac, xbd, o.fa[0] ? o.fa[0] + 4 * f : nullptr,
+           o.fc[0] ? o.fc[0] + 3 * f : nullptr);
+  }
+  if (i < ni && k < nk && (o.fa[1] || o.fc[1])) {          // j-face, plot3d.cpp:224-255
+    nd(i, j, k, n00); nd(i + 1, j, k, n10); nd(i, j, k + 1, n01); nd(i + 1, j, k + 1, n11);
+    m_sub(n01, n10, xac); m_sub(n00, n11, xbd);
+    const long f = ((long)k * (nj + 1) + j) * ni + i;
+    m_face(n00, n10, n01, n11, xac, xbd, o.fa[1] ? o.fa[1] + 4 * f : nullptr,
+           o.fc[1] ? o.fc[1] + 3 * f : nullptr);
+  }
+  if (i < ni && j < nj && (o.fa[2] || o.fc[2])) {          // k-face, plot3d.cpp:300-331
+    nd(i, j, k, n00); nd(i + 1, j, k, n10); nd(i, j + 1, k, n01); nd(i + 1, j + 1, k, n11);
+    m_sub(n01, n10, xac); m_sub(n11, n00, xbd);
+    const long f = ((long)k * nj + j) * ni + i;
+    m_face(n00, n10, n01, n11, xac, xbd, o.fa[2] ? o.fa[2] + 4 * f : nullptr,
+           o.fc[2] ? o.fc[2] + 3 * f : nullptr);
+  }
+}
+// kdtree::NearestNeighbor (kdtree.cpp:123-225) over the wall face centres, as an exhaustive
+// search: a workgroup keeps 256 cells in registers and streams the wall points through LDS
+// 256 at a time (every thread reads every point of a tile: LDS broadcast reads).
+__global__ void __launch_bounds__(256)
+k_nearest_wall(long ncell, const double* __restrict__ cen, long nwall,
+               const double* __restrict__ wall, double* __restrict__ dist) {
+  __shared__ double sw[256][3];
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  const long qc = min(q, ncell - 1);
+  const double c[3] = {cen[3 * qc], cen[3 * qc + 1], cen[3 * qc + 2]};
+  double best = 1.7976931348623157e308;
+  for (long p0 = 0; p0 < nwall; p0 += 256) {
+    const long p = min(p0 + threadIdx.x, nwall - 1);       // (the last point again: harmless)
+    __syncthreads();
+    sw[threadIdx.x][0] = wall[3 * p]; sw[threadIdx.x][1] = wall[3 * p + 1];
+    sw[threadIdx.x][2] = wall[3 * p + 2];
+    __syncthreads();
+#pragma unroll 8
+    for (int m = 0; m < 256; ++m) {
+      const double d[3] = {c[0] - sw[m][0], c[1] - sw[m][1], c[2] - sw[m][2]};
+      best = fmin(best, dot3(d, d));
+    }
+  }
+  if (q < ncell) dist[q] = sqrt(best);
+}
+
+// ---------------------------------------------------------------------------
 // AoS (reference host layout) <-> SoA conversion at the boundary
 __global__ void k_aos_to_soa(const double* __restrict__ aos, Planes5 soa, int ncomp,
                              int ci, int cj, int ck, int gsrc, BlockDev b) {

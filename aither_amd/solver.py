@@ -63,6 +63,46 @@ class DistExchange:
         return 0
 
 
+class DeviceSetup:
+    """The volume-sized parts of the grid set-up in the library:
+    plot3dBlock's metrics (agx_plot3d_metrics) and the nearest-wall search of
+    CalcWallDistance (agx_nearest_wall_distance).  Handed to case.builder.build_case."""
+
+    def __init__(self, api, device=0):
+        self.api = api
+        self.ctx = C.c_void_p()
+        api.check(api.ctx_create(device, 0, C.byref(self.ctx)), "ctx_create")
+
+    def close(self):
+        if self.ctx:
+            self.api.ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def metrics(self, coords):
+        x = np.ascontiguousarray(coords, dtype=np.float64)
+        nk, nj, ni = (s - 1 for s in x.shape[:3])
+        out = dict(vol=np.empty((nk, nj, ni, 1)), center=np.empty((nk, nj, ni, 3)),
+                   farea_i=np.empty((nk, nj, ni + 1, 4)), farea_j=np.empty((nk, nj + 1, ni, 4)),
+                   farea_k=np.empty((nk + 1, nj, ni, 4)), fcen_i=np.empty((nk, nj, ni + 1, 3)),
+                   fcen_j=np.empty((nk, nj + 1, ni, 3)), fcen_k=np.empty((nk + 1, nj, ni, 3)))
+        p = lambda a: a.ctypes.data_as(abi.c_dp)
+        self.api.check(self.api.plot3d_metrics(
+            self.ctx, ni, nj, nk, p(x), p(out["vol"]), p(out["center"]), p(out["farea_i"]),
+            p(out["farea_j"]), p(out["farea_k"]), p(out["fcen_i"]), p(out["fcen_j"]),
+            p(out["fcen_k"])), "plot3d_metrics")
+        return out
+
+    def nearest(self, cells, walls):
+        cells = np.ascontiguousarray(cells, dtype=np.float64)
+        walls = np.ascontiguousarray(walls, dtype=np.float64)
+        dist = np.empty(len(cells))
+        self.api.check(self.api.nearest_wall_distance(
+            self.ctx, len(cells), cells.ctypes.data_as(abi.c_dp), len(walls),
+            walls.ctypes.data_as(abi.c_dp), dist.ctypes.data_as(abi.c_dp)),
+            "nearest_wall_distance")
+        return dist
+
+
 class Solver:
     def __init__(self, api, case, device=0, rank=0, stream=None, exchange=None,
                  rccl=None):

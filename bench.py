@@ -74,7 +74,7 @@ def deck_kwargs(workload):
                 matrix_sweeps=1, cfl=10.0)
 
 
-def rank_local_chain_case(rank, nranks, n, workload, dims=None):
+def rank_local_chain_case(rank, nranks, n, workload, dims=None, setup=None):
     """Block `rank` of a chain of nranks identical n^3 blocks stacked along k.
     Only this rank's block is built at full size; its neighbours are built
     four cells thick, which is all the ghost-geometry exchange reads."""
@@ -87,7 +87,7 @@ def rank_local_chain_case(rank, nranks, n, workload, dims=None):
         nb = (n // 2, n // 2, n // 4)
         case = synthetic.stacked_blocks_case(n=nb, nblocks=4, axis="i", stretch=1.15, bcs=bcs,
                                              ranks=[b * nranks // 4 for b in range(4)],
-                                             amplitude=0.01, **kw)
+                                             amplitude=0.01, setup=setup, **kw)
         # a flat plate: free stream along the wall, a 1/7-th power boundary-layer profile
         # of thickness 0.05 over it, 1 % perturbation -- the k-omega model develops the
         # layer without leaving its stable range (oracle: residuals fall monotonically in
@@ -102,7 +102,8 @@ def rank_local_chain_case(rank, nranks, n, workload, dims=None):
     if workload == "dplur8":
         # BASELINE configs[3]: 2 x 2 x 2 blocks of (n/2)^3 cells, 8 / nranks per rank
         case = synthetic.cube_blocks_case(n=(n // 2,) * 3, splits=(2, 2, 2),
-                                          ranks=[b * nranks // 8 for b in range(8)], **kw)
+                                          ranks=[b * nranks // 8 for b in range(8)],
+                                          setup=setup, **kw)
         case.total_cells = 8 * (n // 2) ** 3
         return case
     bcs = None
@@ -111,7 +112,7 @@ def rank_local_chain_case(rank, nranks, n, workload, dims=None):
                2: ("characteristic", 1), 4: ("characteristic", 1)}
     if nranks == 1:
         return synthetic.single_block_case(dims or (n, n, n), stretch=1.2, bcs=bcs,
-                                           amplitude=0.05, **kw)
+                                           amplitude=0.05, setup=setup, **kw)
     deck = synthetic.make_deck(**kw)
     thin = 4
     coords, all_bcs, dims = [], [], []
@@ -153,7 +154,7 @@ def rank_local_chain_case(rank, nranks, n, workload, dims=None):
                     s.bc_type, s.tag = "slipWall", 0
     deck.bcs = sub_deck_bcs
     case = _b.build_case(None, deck=deck, coords=[coords[b] for b in keep],
-                         ranks=keep)
+                         ranks=keep, setup=setup)
     # rank ids are the global block ids (one block per rank)
     for c in case.connections:
         c.rank = [keep[c.block[0]], keep[c.block[1]]]
@@ -283,7 +284,12 @@ def run_workload(args, workload, api, world, rank, local_rank):
     measured quantities of this rank (rank 0 holds the max-over-ranks time)."""
     n = args.size
     dims = tuple(int(v) for v in args.dims.split(",")) if args.dims else None
-    case = rank_local_chain_case(rank, world, n, workload, dims)
+    # the volume-sized parts of the grid set-up (metrics, wall distance) run in the library
+    # too (agx_plot3d_metrics, agx_nearest_wall_distance; outside the timed region)
+    from aither_amd.solver import DeviceSetup
+    setup = DeviceSetup(api, device=local_rank)
+    case = rank_local_chain_case(rank, world, n, workload, dims, setup=setup)
+    setup.close()
     nonlin = case.deck.nonlinear_iterations
     transport = "none"
     if world > 1 and args.backend == "nccl":

@@ -321,6 +321,28 @@ int agx_output_pack(agx_ctx *ctx, int block, int nvar, const int32_t *vars, doub
  * solution of multilevel time integration: conserved variables, :700-750). */
 int agx_restart_pack(agx_ctx *ctx, int block, int which, double *out);
 
+/* ---- set-up: the volume-sized parts of the reference's grid set-up -------
+ * plot3dBlock::Volume / Centroid / FaceAreaI,J,K / FaceCenterI,J,K (plot3d.cpp:35-360) of
+ * one block from its node coordinates nodes[nk+1][nj+1][ni+1][3] (i fastest, as
+ * plot3dBlock holds them).  Outputs in the reference's layout, physical cells / faces only
+ * (ghost geometry -- PadWithGhosts, AssignGhostCellsGeom, SwapGeomSlice: surface-sized
+ * work -- stays with the caller): vol[nk][nj][ni], center[nk][nj][ni][3],
+ * farea_i[nk][nj][ni+1][4] = {unit normal, |A|}, fcenter_i[nk][nj][ni+1][3], the j- and
+ * k-face arrays with the extra entry in their own direction.  Any output may be NULL.
+ * Host pointers; needs neither a configuration nor blocks. */
+int agx_plot3d_metrics(agx_ctx *ctx, int ni, int nj, int nk, const double *nodes,
+                       double *vol, double *center, double *farea_i, double *farea_j,
+                       double *farea_k, double *fcenter_i, double *fcenter_j,
+                       double *fcenter_k);
+/* kdtree::NearestNeighbor over the viscous-wall face centres (kdtree.cpp:123-225 as
+ * main.cpp:191-203 / procBlock::CalcWallDistance procBlock.cpp:6030-6042 use it): for
+ * each of ncell points (x, y, z) the distance to the nearest of nwall points.  On the
+ * device an exhaustive search tiled through LDS (no tree: 16.7 M cells x 65 k wall faces is
+ * a fraction of a second).  The ghost-cell rule of CalcWallDistance (:6044-6107) and
+ * SwapWallDist are surface-sized and stay with the caller.  Host pointers. */
+int agx_nearest_wall_distance(agx_ctx *ctx, int64_t ncell, const double *cell_centres,
+                              int64_t nwall, const double *wall_points, double *dist);
+
 /* halo exchange (multiArray3d.hpp:790-873 SwapSliceLocal / SwapSliceParallel).
  * local: both sides on this rank. */
 int agx_halo_swap_local(agx_ctx *ctx, int what);

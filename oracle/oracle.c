@@ -2987,6 +2987,119 @@ int ora_restart_pack(ora_ctx *c, int id, int which, double *out) {
       }
   return 0;
 }
+/* ---- set-up: plot3dBlock metrics (plot3d.cpp:35-360) ------------------------ */
+static void v_sub(const double *a, const double *b, double *o) {
+  o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2];
+}
+static void v_cross(const double *a, const double *b, double *o) {   /* vector3d.hpp:330-339 */
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = -1.0 * (a[0] * b[2] - a[2] * b[0]);
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double pyramid_volume(const double *p, const double *a, const double *b,
+                             const double *cc, const double *d) {   /* plot3d.cpp:490-498 */
+  double xp[3], xac[3], xbd[3], cr[3], t[3];
+  for (int q = 0; q < 3; ++q) {
+    t[q] = (a[q] - p[q]) + (b[q] - p[q]);
+    t[q] = t[q] + (cc[q] - p[q]);
+    t[q] = t[q] + (d[q] - p[q]);
+    xp[q] = 0.25 * t[q];
+  }
+  v_sub(cc, a, xac);
+  v_sub(d, b, xbd);
+  v_cross(xac, xbd, cr);
+  return 1.0 / 6.0 * dot3(xp, cr);
+}
+static void face_area_center(const double *n00, const double *n10, const double *n01,
+                             const double *n11, const double *xac, const double *xbd,
+                             double *fa, double *fc) {
+  double cr[3];
+  v_cross(xbd, xac, cr);
+  const double h[3] = {0.5 * cr[0], 0.5 * cr[1], 0.5 * cr[2]};
+  const double mag = sqrt(dot3(h, h));
+  if (fa) { fa[0] = h[0] / mag; fa[1] = h[1] / mag; fa[2] = h[2] / mag; fa[3] = mag; }
+  if (fc)
+    for (int q = 0; q < 3; ++q) fc[q] = 0.25 * (((n00[q] + n10[q]) + n01[q]) + n11[q]);
+}
+int ora_plot3d_metrics(ora_ctx *c, int ni, int nj, int nk, const double *x, double *vol,
+                       double *center, double *fai, double *faj, double *fak, double *fci,
+                       double *fcj, double *fck) {
+  (void)c;
+  if (ni < 1 || nj < 1 || nk < 1) return fail("empty block");
+#define ND(i, j, k) (x + 3 * (((long)(k) * (nj + 1) + (j)) * (ni + 1) + (i)))
+  for (int k = 0; k <= nk; ++k)
+    for (int j = 0; j <= nj; ++j)
+      for (int i = 0; i <= ni; ++i) {
+        if (i < ni && j < nj && k < nk && (vol || center)) {
+          const double *c000 = ND(i, j, k), *c100 = ND(i + 1, j, k), *c010 = ND(i, j + 1, k),
+                       *c110 = ND(i + 1, j + 1, k), *c001 = ND(i, j, k + 1),
+                       *c101 = ND(i + 1, j, k + 1), *c011 = ND(i, j + 1, k + 1),
+                       *c111 = ND(i + 1, j + 1, k + 1);
+          double cen[3];
+          for (int q = 0; q < 3; ++q)      /* plot3d.cpp:35-43 */
+            cen[q] = 0.125 * (((((((c000[q] + c100[q]) + c010[q]) + c110[q]) + c001[q]) +
+                                c101[q]) + c011[q]) + c111[q]);
+          const long p = ((long)k * nj + j) * ni + i;
+          if (center) memcpy(center + 3 * p, cen, sizeof cen);
+          if (vol) {                        /* plot3d.cpp:60-113, the same pyramid order */
+            double v = pyramid_volume(cen, c000, c001, c011, c010);
+            v = v + pyramid_volume(cen, c100, c110, c111, c101);
+            v = v + pyramid_volume(cen, c000, c100, c101, c001);
+            v = v + pyramid_volume(cen, c010, c011, c111, c110);
+            v = v + pyramid_volume(cen, c000, c010, c110, c100);
+            v = v + pyramid_volume(cen, c001, c101, c111, c011);
+            if (v <= 0.0) return fail("negative volume in PLOT3D block");
+            vol[p] = v;
+          }
+        }
+        double xac[3], xbd[3];
+        if (j < nj && k < nk && (fai || fci)) {      /* i-faces, plot3d.cpp:150-181 */
+          const double *n00 = ND(i, j, k), *n10 = ND(i, j + 1, k), *n01 = ND(i, j, k + 1),
+                       *n11 = ND(i, j + 1, k + 1);
+          v_sub(n11, n00, xac); v_sub(n10, n01, xbd);
+          const long f = ((long)k * nj + j) * (ni + 1) + i;
+          face_area_center(n00, n10, n01, n11, xac, xbd, fai ? fai + 4 * f : NULL,
+                           fci ? fci + 3 * f : NULL);
+        }
+        if (i < ni && k < nk && (faj || fcj)) {      /* j-faces, plot3d.cpp:224-255 */
+          const double *n00 = ND(i, j, k), *n10 = ND(i + 1, j, k), *n01 = ND(i, j, k + 1),
+                       *n11 = ND(i + 1, j, k + 1);
+          v_sub(n01, n10, xac); v_sub(n00, n11, xbd);
+          const long f = ((long)k * (nj + 1) + j) * ni + i;
+          face_area_center(n00, n10, n01, n11, xac, xbd, faj ? faj + 4 * f : NULL,
+                           fcj ? fcj + 3 * f : NULL);
+        }
+        if (i < ni && j < nj && (fak || fck)) {      /* k-faces, plot3d.cpp:300-331 */
+          const double *n00 = ND(i, j, k), *n10 = ND(i + 1, j, k), *n01 = ND(i, j + 1, k),
+                       *n11 = ND(i + 1, j + 1, k);
+          v_sub(n01, n10, xac); v_sub(n11, n00, xbd);
+          const long f = ((long)k * nj + j) * ni + i;
+          face_area_center(n00, n10, n01, n11, xac, xbd, fak ? fak + 4 * f : NULL,
+                           fck ? fck + 3 * f : NULL);
+        }
+      }
+#undef ND
+  return 0;
+}
+/* kdtree::NearestNeighbor (kdtree.cpp:123-225) as CalcWallDistance uses it: the distance
+ * to the nearest point of the set -- here by exhaustive search (what the tree computes) */
+int ora_nearest_wall_distance(ora_ctx *c, int64_t ncell, const double *cen, int64_t nwall,
+                              const double *wall, double *dist) {
+  (void)c;
+  if (nwall < 1) return fail("no wall points");
+#pragma omp parallel for schedule(static) if (ncell * nwall > 4000000)
+  for (int64_t q = 0; q < ncell; ++q) {
+    double best = 1.7976931348623157e308;
+    for (int64_t p = 0; p < nwall; ++p) {
+      const double d[3] = {cen[3 * q] - wall[3 * p], cen[3 * q + 1] - wall[3 * p + 1],
+                           cen[3 * q + 2] - wall[3 * p + 2]};
+      const double d2 = dot3(d, d);
+      if (d2 < best) best = d2;
+    }
+    dist[q] = sqrt(best);
+  }
+  return 0;
+}
 int ora_field_upload(ora_ctx *c, int id, int field, const double *in) {
   if (id < 0 || id >= c->nblk) return fail("bad block id");
   long n;

@@ -37,6 +37,12 @@ int ora_field_download(ora_ctx *ctx, int block_id, int field, double *out);
 int ora_field_upload(ora_ctx *ctx, int block_id, int field, const double *in);
 int ora_output_pack(ora_ctx *ctx, int block_id, int nvar, const int32_t *vars, double *out);
 int ora_restart_pack(ora_ctx *ctx, int block_id, int which, double *out);
+int ora_plot3d_metrics(ora_ctx *ctx, int ni, int nj, int nk, const double *nodes,
+                       double *vol, double *center, double *farea_i, double *farea_j,
+                       double *farea_k, double *fcenter_i, double *fcenter_j,
+                       double *fcenter_k);
+int ora_nearest_wall_distance(ora_ctx *ctx, int64_t ncell, const double *cell_centres,
+                              int64_t nwall, const double *wall_points, double *dist);
 int ora_store_time_n(ora_ctx *ctx, int also_nm1);
 int ora_iterate(ora_ctx *ctx, int mm, double cfl, double *l2, agx_linf *linf,
                 double *matrix_resid);

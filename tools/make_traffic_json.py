@@ -15,9 +15,10 @@ METHOD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
           "(tools/profile_round.sh); FETCH_SIZE KB x1024 x2 (gfx950 counts 128-B requests "
           "at 64 B; tools/hbm_calib.hip: 1 GiB streamed read reports 524292.5 KB, 1 GiB "
           "streamed write 1048576 KB), WRITE_SIZE KB x1024")
-PASS_OF = [("k_residual_tile", "R"), ("k_visc", "R"), ("k_lusgs_prepare", "R"),
-           ("k_implicit_begin", "R"), ("k_lusgs_kp", "F+B"), ("k_dplur", "4"),
-           ("k_matrix_resid", "M"), ("k_update", "U"), ("k_norm_final", "U")]
+PASS_OF = [("k_residual_tile", "R"), ("k_inv_residual", "R"), ("k_block_diag", "R"),
+           ("k_visc", "R"), ("k_lusgs_prepare", "R"), ("k_implicit_begin", "R"),
+           ("k_sweep_records", "F+B"), ("k_lusgs_kp", "F+B"), ("k_lusgs_plane", "F+B"),
+           ("k_dplur", "4"), ("k_matrix_resid", "M"), ("k_update", "U"), ("k_norm_final", "U")]
 
 
 def bytes_of(v):
@@ -37,7 +38,8 @@ if os.path.exists(path):
         "(stage-0 variant that also stores consVarsN weighted 1 in 4)",
         "bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
         "algorithmic_bytes": 296 * 256 ** 3, "method": METHOD, "source": path}
-for wl, cells in (("lusgs", 256 ** 3), ("dplur8", 8 * 128 ** 3)):
+RANS_BYTES = 8 * ((7 + 19 + 7 + 3 + 29) + 2 * (7 * 7 + 19 + 29 + 7) + (7 * 7 + 19 + 29) + 3 * 7)
+for wl, cells in (("lusgs", 256 ** 3), ("dplur8", 8 * 128 ** 3), ("rans4", 4 * 128 * 128 * 64)):
     path = f"profiles/{rnd}_{wl}_pmc_traffic.json"
     if not os.path.exists(path):
         continue
@@ -54,7 +56,7 @@ for wl, cells in (("lusgs", 256 ** 3), ("dplur8", 8 * 128 ** 3)):
                 break
     out[wl] = {"cells": cells, "bytes_per_iteration": total, "passes": passes,
                "kernels": kernels,
-               "algorithmic_bytes": (1296 if wl == "lusgs" else 1960) * cells,
+               "algorithmic_bytes": {"lusgs": 1296, "dplur8": 1960, "rans4": RANS_BYTES}[wl] * cells,
                "method": METHOD, "source": path}
 json.dump(out, open("profiles/hbm_traffic.json", "w"), indent=1)
 for k, v in out.items():
