@@ -101,6 +101,10 @@ def make_deck(**kw):
                             lengthScale=1.0)),
         State("pressureOutlet", dict(tag=7, pressure=101325.0, nonreflecting=True,
                                      lengthScale=1.0)),
+        State("supersonicInflow", dict(tag=8, pressure=101325.0, density=1.225,
+                                       velocity=vel, **turb)),
+        State("supersonicOutflow", dict(tag=9)),
+        State("inlet", dict(tag=10, pressure=101325.0, density=1.225, velocity=vel, **turb)),
     ]
     return d
 

@@ -1360,7 +1360,10 @@ int agx_conn_create(agx_ctx* c, const agx_connection* cc, int* conn_id) {
 }
 
 // workgroups of k_matrix_resid_d2: 8 XCDs x mresid_split bands x chunks per band x nk
-constexpr int MRESID_KC = 32;   // planes a workgroup of k_matrix_resid_d2m marches
+#ifndef AGX_MRESID_KC
+#define AGX_MRESID_KC 32
+#endif
+constexpr int MRESID_KC = AGX_MRESID_KC;   // planes a workgroup of k_matrix_resid_d2m marches
 long mresid_wgs(const agx_ctx* c, const BlockDev& b) {
   const long nchunk = ((long)b.d2.Pi * b.d2.Pj + 255) / 256;
   if (c->mresid_march) return 8L * ((nchunk + 7) / 8) * ((b.nk + MRESID_KC - 1) / MRESID_KC);

@@ -890,11 +890,6 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
                                    double wall_dist, double* gh,
                                    const NrDev* nr = nullptr, double nu_w = 0.0,
                                    WallVars* wv = nullptr) {
-  // rans: the other boundary types are not built (as in the oracle)
-  if (AGX_NEQ > 5 && bc != AGX_BC_SLIPWALL && bc != AGX_BC_VISCOUSWALL &&
-      bc != AGX_BC_CHARACTERISTIC && bc != AGX_BC_STAGNATION_INLET &&
-      bc != AGX_BC_PRESSURE_OUTLET)
-    return false;
 #pragma unroll
   for (int e = 0; e < AGX_NEQ; ++e) gh[e] = in[e];
   const double sgn = (surf % 2 == 1) ? -1.0 : 1.0;
@@ -998,6 +993,8 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
           for (int q = 0; q < 3; ++q)
             gh[1 + q] = (nr->sn[1 + q] + nr->dt * kk * fs[1 + q] - n[q] * dpn / rcN) /
                         (1.0 + nr->dt * kk);
+          // (reflecting and nonreflecting alike, ghostStates.cpp:475-479)
+          apply_farfield_turb(g, gh, fs + 1, d.turb_intensity, d.eddy_visc_ratio);
         } else {
           const double dp = fs[4] - gh[4];
           gh[0] = fs[0] - dp / (c * c);
@@ -1018,8 +1015,10 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
         if (layer > 1) {
           extrap_hold(gh, (double)layer, in, t);
           for (int e = 0; e < AGX_NEQ; ++e) gh[e] = t[e];
-          // (whatever the flow direction, ghostStates.cpp:381-387)
-          apply_farfield_turb(g, gh, fs + 1, d.turb_intensity, d.eddy_visc_ratio);
+          // (characteristic: whatever the flow direction, ghostStates.cpp:381-387; the
+          // inlet's deeper layers are only extrapolated, :481-486)
+          if (bc == AGX_BC_CHARACTERISTIC)
+            apply_farfield_turb(g, gh, fs + 1, d.turb_intensity, d.eddy_visc_ratio);
         }
       }
       return true;
@@ -1027,6 +1026,7 @@ __device__ inline bool ghost_state(const GasDev& g, const double* in, int bc,
     case AGX_BC_SUPERSONIC_INFLOW:
       gh[0] = d.density; gh[1] = d.velocity[0]; gh[2] = d.velocity[1];
       gh[3] = d.velocity[2]; gh[4] = d.pressure;
+      apply_farfield_turb(g, gh, d.velocity, d.turb_intensity, d.eddy_visc_ratio);   // :513-517
       return true;
     case AGX_BC_SUPERSONIC_OUTFLOW:
       if (layer > 1)

@@ -1233,21 +1233,34 @@ __device__ __forceinline__ void visc_face_terms(const BlockDev& b, const GasDev&
   if (fourth) {
     // FaceReconCentral4th reconstruction.hpp:335-379, LagrangeCoeff(w, 3, 1, 1);
     // state and viscosity of the four cells around the face (procBlock.cpp:1325-1346)
+    // In Newton form on the divided differences of the four cell values (as the WENO
+    // stencils, agx_device.hpp): with the face at the upper edge of cell 1,
+    //   f = u1 + w1 G12 - w1 w2 D3a - w1 w2 (w0 + w1) D4,
+    //   Gab = (ub - ua) / (wa + wb),  D3a = (G12 - G01) / (w0 + w1 + w2),
+    //   D3b = (G23 - G12) / (w1 + w2 + w3),  D4 = (D3b - D3a) / (w0 + w1 + w2 + w3)
+    // (uniform widths: -1/12, 7/12, 7/12, -1/12).  Formula 2.20's generic loops unrolled to
+    // 3.3 KB of scratch per lane in this kernel.
     const long qs[4] = {qL - sd, qL, qU, qU + sd};
-    const double w4[4] = {b.wid[d][qs[0]], b.wid[d][qs[1]], b.wid[d][qs[2]], b.wid[d][qs[3]]};
-    double cf[4];
-    lagrange_coeff<3>(w4, 1, 1, cf);
-    muf = 0.0;
-#pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) sf[e] = 0.0;
+    const double w0 = b.wid[d][qs[0]], w1 = b.wid[d][qs[1]], w2 = b.wid[d][qs[2]],
+                 w3 = b.wid[d][qs[3]];
+    const double r01 = 1.0 / (w0 + w1), r12 = 1.0 / (w1 + w2), r23 = 1.0 / (w2 + w3);
+    const double t012 = 1.0 / (w0 + w1 + w2), t123 = 1.0 / (w1 + w2 + w3);
+    const double q4 = 1.0 / ((w0 + w1) + (w2 + w3));
+    const double k3 = w1 * w2, k4 = k3 * (w0 + w1);
+    auto c4 = [&](double u0, double u1, double u2, double u3) {
+      const double g01 = (u1 - u0) * r01, g12 = (u2 - u1) * r12, g23 = (u3 - u2) * r23;
+      const double d3a = (g12 - g01) * t012, d3b = (g23 - g12) * t123;
+      return u1 + w1 * g12 - k3 * d3a - k4 * ((d3b - d3a) * q4);
+    };
+    double s4[4][AGX_NEQ], mu4[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      double s4[AGX_NEQ];
-      load5(b.state, qs[m], s4);
-#pragma unroll
-      for (int e = 0; e < AGX_NEQ; ++e) sf[e] += cf[m] * s4[e];
-      muf += cf[m] * viscosity(g, temperature(g, s4));
+      load5(b.state, qs[m], s4[m]);
+      mu4[m] = viscosity(g, temperature(g, s4[m]));
     }
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) sf[e] = c4(s4[0][e], s4[1][e], s4[2][e], s4[3][e]);
+    muf = c4(mu4[0], mu4[1], mu4[2], mu4[3]);
   } else {
     const double wU = b.wid[d][qL], wD = b.wid[d][qU];
     const double cD = wD / (wU + wD), cU = wU / (wU + wD);

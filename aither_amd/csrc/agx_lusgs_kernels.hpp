@@ -721,7 +721,10 @@ k_matrix_resid_d2(BlockDev b, GasDev g, SolverDev sp, int nsplit, NormPartial* p
 // in-plane neighbours come from the arrays (rows of the adjacent diagonals, which the
 // neighbouring chunks of the same XCD band are reading as their own at the same time).
 // Grid: (position chunk, k-chunk) pairs, a contiguous band of chunks per XCD.
-__global__ void __launch_bounds__(256)
+#ifndef AGX_MR_WAVES
+#define AGX_MR_WAVES 1
+#endif
+__global__ void __launch_bounds__(256, AGX_MR_WAVES)
 k_matrix_resid_d2m(BlockDev b, GasDev g, SolverDev sp, int kc, NormPartial* partials) {
   const D2Dev& z = b.d2;
   const int nchunk = (z.Pi * z.Pj + 255) / 256;

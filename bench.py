@@ -561,8 +561,11 @@ def main():
     extra = None
     if args.workload == "lusgs" and world == 1 and not args.no_extra and not args.dims:
         # the explicit-RK4 residual sweep the ">= 40 % of roofline" target is stated on
+        # (48 warm-up stages: the stage kernel runs 1.9 ms right after set-up and settles
+        # at 1.46-1.5 ms some 60 ms later -- clocks and TLBs -- see the per-launch times in
+        # profiles/r03_rk4_kernel_trace_durations.txt; 8 stages were 13 ms)
         rk_args = argparse.Namespace(**vars(args))
-        rk_args.steps, rk_args.warmup = max(args.steps, 40), max(args.warmup, 8)
+        rk_args.steps, rk_args.warmup = max(args.steps, 80), max(args.warmup, 48)
         extra = ("rk4", rk_args, run_workload(rk_args, "rk4", api, world, rank, local_rank))
     elif (args.workload == "lusgs" and world > 1 and 8 % world == 0 and not args.no_extra
           and not args.dims):

@@ -787,10 +787,6 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
                           const agx_bc_state *d, int layer, double wallDist, double nuW,
                           const nr_data *nr, wall_vars *wv, double *ghost) {
   const int rans = NEQ > NF;
-  if (rans && bc != AGX_BC_SLIPWALL && bc != AGX_BC_VISCOUSWALL && bc != AGX_BC_CHARACTERISTIC &&
-      bc != AGX_BC_STAGNATION_INLET && bc != AGX_BC_PRESSURE_OUTLET)
-    return fail("rans: boundary type %d is not restated (slipWall, viscousWall, "
-                "characteristic, stagnationInlet, pressureOutlet, interblock, periodic are)", bc);
   for (int e = 0; e < NEQ; ++e) ghost[e] = interior[e];
   const int isLower = surf % 2 == 1;
   double n[3];
@@ -916,6 +912,8 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
     const double machInt = fabs(velIntNorm) / SoSInt;
     if (machInt >= 1.0) {
       for (int e = 0; e < NEQ; ++e) ghost[e] = fs[e];
+      /* ghostStates.cpp:419-423 */
+      if (rans) apply_farfield_turb(c, ghost, fs + 1, d->turb_intensity, d->eddy_visc_ratio);
     } else {
       const double rhoSoSInt = interior[0] * SoSInt;
       double velDiff[3] = {fs[1] - interior[1], fs[2] - interior[2],
@@ -942,6 +940,8 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
       ghost[2] = fs[2] - n[1] * dP / rhoSoSInt;
       ghost[3] = fs[3] - n[2] * dP / rhoSoSInt;
       }
+      /* ghostStates.cpp:475-479 (reflecting and nonreflecting alike) */
+      if (rans) apply_farfield_turb(c, ghost, fs + 1, d->turb_intensity, d->eddy_visc_ratio);
       double tmp[NEQM];
       extrap_hold(ghost, 2.0, interior, tmp);
       memcpy(ghost, tmp, sizeof(double) * NEQ);
@@ -957,6 +957,8 @@ static int ghost_state_nr(const ora_ctx *c, const double *interior, int bc,
     ghost[2] = d->velocity[1];
     ghost[3] = d->velocity[2];
     ghost[4] = d->pressure;
+    /* ghostStates.cpp:513-517 */
+    if (rans) apply_farfield_turb(c, ghost, d->velocity, d->turb_intensity, d->eddy_visc_ratio);
   } else if (bc == AGX_BC_SUPERSONIC_OUTFLOW) {
     if (layer > 1)
       for (int e = 0; e < NEQ; ++e) ghost[e] = layer * ghost[e] - interior[e];

@@ -854,6 +854,21 @@ def test_rans_synthetic_parity(agx_rans, oracle, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("vel", [(50.0, 20.0, 10.0), (420.0, 20.0, 10.0)])
+def test_rans_inlet_and_supersonic_boundaries_parity(agx_rans, oracle, vel):
+    """rans ghost states of inlet (subsonic: characteristics both ways; supersonic: the free
+    stream), supersonicInflow and supersonicOutflow with their farfield turbulence
+    (ghostStates.cpp:392-533), beside a viscous wall, a characteristic far field and a
+    pressure outlet -- at a subsonic and a supersonic free stream."""
+    bcs = {1: ("supersonicInflow", 8), 2: ("supersonicOutflow", 9), 3: ("viscousWall", 2),
+           4: ("characteristic", 1), 5: ("inlet", 10), 6: ("pressureOutlet", 3)}
+    case = synthetic.single_block_case(n=(9, 8, 7), stretch=1.2, bcs=bcs, equation_set="rans",
+                                       turbulence_model="sst2003", velocity=list(vel),
+                                       time_integration="implicitEuler", cfl=5.0)
+    _close(*run_pair(agx_rans, oracle, case, 3))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("solver", ["lusgs", "blusgs"])
 def test_rans_stacked_blocks_parity(agx_rans, oracle, solver):
     """rans across interblock connections: the ghost eddy viscosity and blending
