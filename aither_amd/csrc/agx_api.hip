@@ -67,6 +67,7 @@ struct Block {
 };
 
 struct ConnSide {          // what side s receives / sends
+  std::vector<long> h_dst, h_src;   // host copies (SoA index space) until agx_setup_finalize is done
   long n = 0;              // cells inserted into side s
   long* dst = nullptr;     // device: ghost cells of side s (this rank's block)
   long* src = nullptr;     // device: partner cells that fill them
@@ -148,6 +149,18 @@ struct agx_ctx {
   BlockDev* blocks_tab_host = nullptr;   // pinned
   size_t blocks_tab_n = 0;
   hipGraphExec_t sweep_graph_all[2][2][2] = {};
+  // local connections exchanged in one gather + one scatter launch (AGX_HALO_BATCH=0: a
+  // launch pair per connection).  Legal when no slice reads a cell another connection's
+  // insert writes (checked at agx_setup_finalize); tables per halo selector in device memory
+  bool halo_batch = true;
+  int halo_batch_sides = 0;
+  long halo_batch_nmax = 0;
+  // the state (fused explicit stages) and x (DPLUR) alternate between two sets of planes:
+  // one table pair per set, built once each
+  HaloSide* halo_tab_dev[5][2][2] = {};   // [what][plane set][gather | scatter]
+  bool halo_tab_valid[5][2] = {};
+  int halo_set[5] = {};
+  HaloSide* halo_tab_host = nullptr;      // pinned staging, 2 * sides entries
   int mresid_split = 1;      // bands of diagonals per XCD in k_matrix_resid_d2 (AGX_MRESID_SPLIT)
   bool mresid_march = true;  // AGX_MRESID=plane: one plane position per thread (comparison form)
   bool have_time_n = false;  // agx_store_time_n has run (nonreflecting BCs read consVarsN)
@@ -366,6 +379,7 @@ int ensure_halo_buf(agx_ctx* c, long ndoubles) {
   if (c->halo_buf) HIPCHK(hipFree(c->halo_buf));
   HIPCHK(hipMalloc((void**)&c->halo_buf, sizeof(double) * ndoubles));
   c->halo_cap = ndoubles;
+  for (auto& v : c->halo_tab_valid) v[0] = v[1] = false;   // (the tables hold slices of this buffer)
   return 0;
 }
 
@@ -899,6 +913,7 @@ int update_pass(agx_ctx* c, int mode, int mm, double* l2, agx_linf* linf) {
       off += mp.nparts;
       for (int e = 0; e < AGX_NEQ; ++e) std::swap(b.state[e], b.state2[e]);
     }
+    c->halo_set[AGX_HALO_STATE] ^= 1;              // (the tables hold plane pointers)
     c->fused_pending = false;
     HIPCHK(hipGetLastError());
   } else {
@@ -1002,6 +1017,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_SWEEP_RECORDS")) c->sweep_records = atoi(w) != 0;
     if (const char* w = getenv("AGX_MRESID_SPLIT")) c->mresid_split = std::min(64, std::max(1, atoi(w)));
     if (const char* w = getenv("AGX_MRESID")) c->mresid_march = strcmp(w, "plane") != 0;
+    if (const char* w = getenv("AGX_HALO_BATCH")) c->halo_batch = atoi(w) != 0;
   }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
   HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
@@ -1061,6 +1077,11 @@ void agx_ctx_destroy(agx_ctx* c) {
   drop_sweep_graphs_all(c);
   if (c->blocks_tab) hipFree(c->blocks_tab);
   if (c->blocks_tab_host) hipHostFree(c->blocks_tab_host);
+  if (c->halo_tab_host) hipHostFree(c->halo_tab_host);
+  for (int w = 0; w < 5; ++w)
+    for (int st = 0; st < 2; ++st)
+      for (int q = 0; q < 2; ++q)
+        if (c->halo_tab_dev[w][st][q]) hipFree(c->halo_tab_dev[w][st][q]);
   for (auto ev : c->branch_events) hipEventDestroy(ev);
   for (auto st : c->branch_streams) hipStreamDestroy(st);
   delete c;
@@ -1371,6 +1392,88 @@ long mresid_wgs(const agx_ctx* c, const BlockDev& b) {
   return bands * ((nchunk + bands - 1) / bands) * b.nk;
 }
 
+namespace {
+// May all local connections be exchanged as "all slices, then all inserts"?  The reference
+// takes them one after the other (multiArray3d.hpp:790-828): a later slice would see an
+// earlier insert if it read a cell that insert writes.  Slices read physical cells except
+// where a patch borders another connection; checked here cell by cell.
+int halo_batch_plan(agx_ctx* c, long* max_halo) {
+  int sides = 0;
+  long total = 0, nmax = 0;
+  std::vector<std::vector<char>> is_dst(c->blocks.size());
+  for (auto& k : c->conns) {
+    const agx_connection& cc = k.c;
+    for (int s = 0; s < 2; ++s) {
+      if (cc.rank[s] != c->rank) continue;
+      auto& flags = is_dst[cc.local_block[s]];
+      if (flags.empty()) flags.assign((size_t)c->blocks[cc.local_block[s]].d.nplane, 0);
+      for (long q : k.side[s].h_dst) flags[(size_t)q] = 1;
+    }
+  }
+  bool ok = true;
+  for (auto& k : c->conns) {
+    const agx_connection& cc = k.c;
+    if (!(cc.rank[0] == c->rank && cc.rank[1] == c->rank)) continue;
+    for (int s = 0; s < 2; ++s) {
+      const auto& flags = is_dst[cc.local_block[1 - s]];      // side s reads the partner block
+      for (long q : k.side[s].h_src) ok = ok && !flags[(size_t)q];
+      total += k.side[s].n;
+      nmax = std::max(nmax, k.side[s].n);
+    }
+    sides += 2;
+  }
+  for (auto& k : c->conns)
+    for (int s = 0; s < 2; ++s) {
+      std::vector<long>().swap(k.side[s].h_dst);
+      std::vector<long>().swap(k.side[s].h_src);
+    }
+  c->halo_batch = c->halo_batch && ok && sides >= 4;
+  if (!c->halo_batch) return 0;
+  c->halo_batch_sides = sides;
+  c->halo_batch_nmax = nmax;
+  *max_halo = std::max(*max_halo, (total * AGX_NEQ + 1) / 2);     // (the buffer is 2 * max_halo)
+  HIPCHK(hipHostMalloc((void**)&c->halo_tab_host, sizeof(HaloSide) * 2 * sides));
+  return 0;
+}
+// the gather / scatter tables of one halo selector (plane pointers of every side)
+int halo_batch_tables(agx_ctx* c, int what) {
+  const int set = c->halo_set[what];
+  if (c->halo_tab_valid[what][set]) return 0;
+  const int sides = c->halo_batch_sides;
+  for (int q = 0; q < 2; ++q)
+    if (!c->halo_tab_dev[what][set][q])
+      HIPCHK(hipMalloc((void**)&c->halo_tab_dev[what][set][q], sizeof(HaloSide) * sides));
+  // (the staging entries may still be read by an earlier copy)
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HaloSide* g = c->halo_tab_host;
+  HaloSide* p = c->halo_tab_host + sides;
+  long off = 0;
+  int n = 0;
+  for (auto& k : c->conns) {
+    const agx_connection& cc = k.c;
+    if (!(cc.rank[0] == c->rank && cc.rank[1] == c->rank)) continue;
+    Block& b0 = c->blocks[cc.local_block[0]];
+    Block& b1 = c->blocks[cc.local_block[1]];
+    const bool z2 = halo_in_d2(b0, what);
+    const long n0 = k.side[0].n, n1 = k.side[1].n;
+    double* buf0 = c->halo_buf + off;
+    double* buf1 = buf0 + n0 * AGX_NEQ;
+    off += (n0 + n1) * AGX_NEQ;
+    g[n] = HaloSide{halo_planes(b1, what), z2 ? k.side[0].src2 : k.side[0].src, n0, buf0};
+    g[n + 1] = HaloSide{halo_planes(b0, what), z2 ? k.side[1].src2 : k.side[1].src, n1, buf1};
+    p[n] = HaloSide{halo_planes(b0, what), z2 ? k.side[0].dst2 : k.side[0].dst, n0, buf0};
+    p[n + 1] = HaloSide{halo_planes(b1, what), z2 ? k.side[1].dst2 : k.side[1].dst, n1, buf1};
+    n += 2;
+  }
+  HIPCHK(hipMemcpyAsync(c->halo_tab_dev[what][set][0], g, sizeof(HaloSide) * sides,
+                        hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->halo_tab_dev[what][set][1], p, sizeof(HaloSide) * sides,
+                        hipMemcpyHostToDevice, c->stream));
+  c->halo_tab_valid[what][set] = true;
+  return 0;
+}
+}  // namespace
+
 int agx_setup_finalize(agx_ctx* c) {
   HIPCHK(hipSetDevice(c->device));
   const int ng = c->cfg.n_ghost;
@@ -1413,6 +1516,8 @@ int agx_setup_finalize(agx_ctx* c) {
         max_halo = std::max(max_halo, (long)ms.src.size() * AGX_NEQ);
       }
       k.side[s].n = (long)m.dst.size();
+      k.side[s].h_dst = m.dst;
+      if (partner_mine) k.side[s].h_src = m.src;
       if (to_device(m.dst, &k.side[s].dst)) return 1;
       if (partner_mine && to_device(m.src, &k.side[s].src)) return 1;
       max_halo = std::max(max_halo, (long)m.dst.size() * AGX_NEQ);
@@ -1437,6 +1542,7 @@ int agx_setup_finalize(agx_ctx* c) {
       }
     }
   }
+  if (halo_batch_plan(c, &max_halo)) return 1;
   if (ensure_halo_buf(c, 2 * max_halo)) return 1;
   // persistent slab pairs of the connections to other ranks (sorted by connection
   // id on every rank: the order RCCL's p2p matching relies on)
@@ -1903,6 +2009,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
                          c->stream, b, c->gas, c->sp);
     }
   }
+  if (!is_lusgs_solver(c)) c->halo_set[AGX_HALO_UPDATE] ^= 1;   // (x and xold changed roles)
   (void)swept;
   HIPCHK(hipGetLastError());
   return 0;
@@ -1982,6 +2089,16 @@ int agx_phase_implicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
 int agx_halo_swap_local(agx_ctx* c, int what) {
   if (c->conns.empty()) return 0;
   Timer t(c, G_BC);
+  if (c->halo_batch && c->halo_batch_sides > 0) {
+    // every slice, then every insert: one launch each (halo_batch_plan)
+    if (halo_batch_tables(c, what)) return 1;
+    const dim3 grid((unsigned)((c->halo_batch_nmax + 255) / 256), (unsigned)c->halo_batch_sides);
+    HaloSide* const* tab = c->halo_tab_dev[what][c->halo_set[what]];
+    hipLaunchKernelGGL(k_halo_gather_all, grid, dim3(256), 0, c->stream, tab[0]);
+    hipLaunchKernelGGL(k_halo_scatter_all, grid, dim3(256), 0, c->stream, tab[1]);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   for (auto& k : c->conns) {
     const agx_connection& cc = k.c;
     if (!(cc.rank[0] == c->rank && cc.rank[1] == c->rank)) continue;

@@ -2053,6 +2053,30 @@ __global__ void k_halo_scatter2(HaloSide s0, HaloSide s1) {
     if (s.a.rec) s.a.rec[q * SW_DYN + SW_X + e] = v;
   }
 }
+// all local connections of a rank in one launch per direction (blockIdx.y: side of the
+// table; the table sits in device memory and is wave-uniform: scalar loads).  A 2 x 2 x 2 cube
+// of blocks has twelve connections and exchanges six times per DPLUR iteration: 72 launch
+// pairs of ~7.5 us each were a tenth of the iteration.
+__global__ void k_halo_gather_all(const HaloSide* __restrict__ tab) {
+  const HaloSide& s = tab[blockIdx.y];
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= s.n) return;
+  const long q = s.map[t];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) s.buf[e * s.n + t] = s.a.p[e][q * s.a.stride];
+}
+__global__ void k_halo_scatter_all(const HaloSide* __restrict__ tab) {
+  const HaloSide& s = tab[blockIdx.y];
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= s.n) return;
+  const long q = s.map[t];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    const double v = s.buf[e * s.n + t];
+    s.a.p[e][q * s.a.stride] = v;
+    if (s.a.rec) s.a.rec[q * SW_DYN + SW_X + e] = v;
+  }
+}
 __global__ void k_halo_gather(Planes5 a, const long* __restrict__ src, long n,
                               double* __restrict__ buf) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;

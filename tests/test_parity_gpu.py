@@ -229,6 +229,38 @@ def test_cube_of_blocks_dplur_parity(agx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dplur", "rk4", "lusgs"])
+def test_batched_local_halo_exchange_is_bitwise_the_sequential_one(agx, kind):
+    """All local connections exchanged in one gather + one scatter launch (default) against a
+    launch pair per connection (AGX_HALO_BATCH=0): 2 x 2 x 2 blocks, twelve connections; DPLUR
+    (x and xold change roles every sweep), the fused RK4 stages (the two state buffers change
+    roles every stage) and LU-SGS (x in the diagonal-ordered arrays)."""
+    kw = {"dplur": dict(inviscid_flux="ausm", limiter="none", time_integration="implicitEuler",
+                        matrix_solver="dplur", matrix_sweeps=3, cfl=5.0),
+          "rk4": dict(time_integration="rk4", cfl=0.5),
+          "lusgs": dict(time_integration="implicitEuler", matrix_solver="lusgs",
+                        matrix_sweeps=2, cfl=5.0)}[kind]
+    case = synthetic.cube_blocks_case(n=(9, 7, 6), splits=(2, 2, 2), **kw)
+    out = {}
+    for mode in ("1", "0"):
+        old = os.environ.get("AGX_HALO_BATCH")
+        os.environ["AGX_HALO_BATCH"] = mode
+        try:
+            s = Solver(agx, case)
+        finally:
+            if old is None:
+                os.environ.pop("AGX_HALO_BATCH", None)
+            else:
+                os.environ["AGX_HALO_BATCH"] = old
+        for nn in range(2):
+            s.step(nn)
+        out[mode] = [s.download("state", gb) for gb in range(8)]
+        s.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_cube_of_blocks_equals_single_block_gpu(agx):
     """Explicit RK4 on 2 x 2 x 2 blocks reproduces the single-block state: the
     halo slabs carry exactly what the fused stage kernel reads."""
