@@ -6,9 +6,28 @@ from aither_amd.solver import Solver
 # fp64 tolerance stated by BASELINE.json north_star: residuals and updated
 # state within 1e-10 relative of the CPU reference.
 RTOL = 1.0e-10
-MATRIX_RTOL = 1.0e-6   # see run_pair: a cancellation remainder, not a field
+MATRIX_RTOL = 1.0e-6   # cap of the bound run_pair DERIVES per case (matrix_tolerance:
+                       # 5e-9 .. 1e-7 for the synthetic decks, cancellation factors 12 .. 270)
 MATRIX_FLOOR = 1.0e-14  # below this the matrix residual of a converged / uniform state
                         # is the round-off of O(1) operands
+
+
+def matrix_tolerance(so):
+    """Relative tolerance of the matrix residual, derived: f - (A x - b) is what is LEFT
+    after its operands A x, the off-diagonal terms and b cancel, so its error is the 1e-10
+    parity of those operands (x, state, residual: asserted field by field in run_pair)
+    amplified by |operands| / |remainder|.  The oracle reports both sums of squares of its
+    last matrix residual (ora_debug_matrix_operands, a test hook); a factor 4 covers the
+    three operands and the square root.  Returns (tolerance, cancellation factor)."""
+    import ctypes as C
+    fn = so.api.lib.ora_debug_matrix_operands
+    fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    ops, res = C.c_double(0.0), C.c_double(0.0)
+    so.api.check(fn(so.ctx, C.byref(ops), C.byref(res)), "debug_matrix_operands")
+    if res.value <= 0.0:
+        return MATRIX_RTOL, float("inf")
+    amp = (ops.value / res.value) ** 0.5
+    return 4.0 * RTOL * amp, amp
 
 
 def rel_err(got, ref, floor=0.0):
@@ -86,13 +105,14 @@ def run_pair(agx, oracle, case, steps, fields=("state", "residual", "dt"),
             assert e < RTOL, ("L2 residual norm", hg["nn"], hg["mm"], e,
                               hg["l2"], ho["l2"])
             if ho["matrix"] > 0:
-                # The matrix residual f - (Ax - b) is what is LEFT after O(1)
-                # terms cancel (1e-7 per cell here against operands of 1e-3), so
-                # its own relative error is the 1e-10 parity of its operands (x,
-                # state, residual -- asserted below) times that cancellation
-                # factor; MATRIX_RTOL states the resulting bound.
-                assert abs(hg["matrix"] - ho["matrix"]) <= MATRIX_RTOL * ho["matrix"] + MATRIX_FLOOR, \
-                    ("matrix residual", hg["matrix"], ho["matrix"])
+                # the last nonlinear iteration of the step against the DERIVED bound (the
+                # hook describes the oracle's last matrix residual), the earlier ones
+                # against its cap
+                last = ho is so.history[-1]
+                tol, amp = matrix_tolerance(so) if last else (MATRIX_RTOL, None)
+                tol = min(tol, MATRIX_RTOL)
+                assert abs(hg["matrix"] - ho["matrix"]) <= tol * ho["matrix"] + MATRIX_FLOOR, \
+                    ("matrix residual", hg["matrix"], ho["matrix"], tol, amp)
         n_hist = len(so.history)
         lg, lo = sg.history[-1]["linf"], so.history[-1]["linf"]
         assert abs(lg[0] - lo[0]) <= RTOL * max(abs(lo[0]), rfloor), (lg, lo)
