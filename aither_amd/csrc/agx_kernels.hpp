@@ -609,6 +609,13 @@ k_residual_march(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
 #else
 #define AGX_AB(bit) (false)
 #endif
+// scheduling barriers of the tile kernel: between the two sides of a WENO face and between
+// the faces of a step (they bound the live ranges; AGX_SB=0 builds without them)
+#ifndef AGX_SB
+#define AGX_SB 3
+#endif
+#define AGX_SB_SIDES do { if (AGX_SB & 1) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define AGX_SB_FACES do { if (AGX_SB & 2) __builtin_amdgcn_sched_barrier(0); } while (0)
 template <int RECON, int LIM, class Get, class GetW>
 __device__ __forceinline__ void recon_generic(Get get, GetW getw, double kappa,
                                               double* l, double* r) {
@@ -643,7 +650,7 @@ __device__ __forceinline__ void recon_generic(Get get, GetW getw, double kappa,
         l[e] = weno<RECON == AGX_RECON_WENOZ>(kc, get(e, -3), get(e, -2), get(e, -1),
                                               get(e, 0), get(e, 1));
     }
-    __builtin_amdgcn_sched_barrier(0);
+    AGX_SB_SIDES;
     {
       double cw[5];
 #pragma unroll
@@ -836,7 +843,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         }
         sr_k = AGX_AB(16) ? 1.0 : specrad(ak_lo, ak_up);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      AGX_SB_FACES;
       // ---- i face (lower): stencil from the LDS plane; the upper face comes
       // from lane + 1 (the tile's right face from the halo wave, below) ----
       {
@@ -871,7 +878,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
           res[e] += (edge ? 0.0 : up) - fi[e];
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      AGX_SB_FACES;
       if (LATE) prefetch();
       // ---- j face (lower): handed to the row below through LDS.  Rows 0 and 1
       // leave this flux to the two halo waves (BAL): the cell waves of those rows
@@ -909,7 +916,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
         }
         sr_j = AGX_AB(16) ? 1.0 : specrad(aj_lo, aj_up);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      AGX_SB_FACES;
       // publish the own entry of the next plane; the loads of the update fly
       // across the barrier
       if (!AGX_AB(64)) {

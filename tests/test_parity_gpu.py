@@ -792,6 +792,55 @@ def test_plane_sweep_forms_agree_bitwise(agx_rans):
 
 
 @pytest.mark.gpu
+def test_rans4_at_bench_size_against_the_simple_forms(agx_rans):
+    """BASELINE configs[4] at the size `bench.py --workload rans4` times (4 blocks of
+    128 x 128 x 64, k-omega SST 2003, BLU-SGS, the flat-plate start): the production sweep
+    form (all blocks per launch, cell-major records, three lanes per cell) against the simple
+    ones -- one lane per cell, and plane-major loads -- bit for bit over four iterations;
+    every norm finite, the run repeatable."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from aither_amd.solver import DeviceSetup
+    setup = DeviceSetup(agx_rans)
+    case = bench.rank_local_chain_case(0, 1, 256, "rans4", setup=setup)
+    setup.close()
+    assert case.n_eq == 7 and case.total_cells == 4 * 128 * 128 * 64
+
+    def run(env, steps):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            s = Solver(agx_rans, case)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        for nn in range(steps):
+            s.step(nn)
+        hist = np.array([np.append(h["l2"], h["matrix"]) for h in s.history])
+        g = case.ng
+        out = [s.download("state", gb)[g:-g, g:-g, g:-g] for gb in range(4)]
+        s.close()
+        return hist, out
+
+    h0, s0 = run({}, 4)
+    assert np.all(np.isfinite(h0)) and np.all(h0[:, -1] > 0.0)
+    for st in s0:
+        assert np.all(np.isfinite(st)) and np.all(st[..., 0] > 0.0) and np.all(st[..., 4] > 0.0)
+    h1, s1 = run({"AGX_SWEEP_THREE": "0"}, 4)
+    assert np.array_equal(h0, h1)
+    for a, b in zip(s0, s1):
+        assert np.array_equal(a, b)
+    h2, s2 = run({"AGX_SWEEP_RECORDS": "0", "AGX_SWEEP_ALL": "0"}, 2)
+    assert np.array_equal(h0[:2], h2)
+    h3, _ = run({}, 4)
+    assert np.array_equal(h0, h3)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag,solver", [(2, "lusgs"), (4, "lusgs"), (5, "lusgs"),
                                         (4, "blusgs"), (5, "blusgs")])
 def test_rans_wall_function_variants_parity(agx_rans, oracle, tag, solver):
