@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AGX_LIB: a diagnostic build of the same library (e.g. -DAGX_KP_TRACE)
 LIB_PATH = os.environ.get("AGX_LIB") or os.path.join(_HERE, "libaither_gfx950.so")
 # the same sources built for the 7-equation set (rans: + k, omega), same C-ABI
-RANS_LIB_PATH = os.path.join(_HERE, "libaither_gfx950_rans.so")
+RANS_LIB_PATH = os.environ.get("AGX_RANS_LIB") or os.path.join(_HERE, "libaither_gfx950_rans.so")
 _api = {}
 
 

@@ -121,6 +121,8 @@ struct agx_ctx {
   long halo_cap = 0;
   double* stage_buf = nullptr;   // AoS staging of uploads / downloads (stage_buffer)
   size_t stage_cap = 0;
+  double* rans_rec = nullptr;    // face records of the rans viscous residual (k_rans_faces),
+  size_t rans_rec_cap = 0;       // sized for the largest block, shared by all of them
   bool use_gather = false;   // AGX_KERNEL=gather: one-thread-per-cell gather kernel
   bool use_tile = true;      // AGX_KERNEL=tile (default) | march
   int num_cu = 256;          // persistent workgroups of the tile kernel
@@ -149,6 +151,15 @@ struct agx_ctx {
   BlockDev* blocks_tab_host = nullptr;   // pinned
   size_t blocks_tab_n = 0;
   hipGraphExec_t sweep_graph_all[2][2][2] = {};
+  // the pipelined half sweep (k_lusgs_pipe): a workgroup per k-plane of every block
+  bool sweep_pipe = true;                // AGX_SWEEP_PIPE=0: one launch per hyperplane
+  PipeJob* pipe_jobs[2] = {nullptr, nullptr};   // device: pipeline order back / forward
+  int* pipe_slot0 = nullptr;             // device
+  long long* pipe_progress = nullptr;    // device, 16 words per plane
+  unsigned long long* pipe_ticket = nullptr;
+  size_t pipe_nblocks = 0;
+  int pipe_njobs = 0, pipe_maxsteps = 0, pipe_waves = 4;
+  long long pipe_launches = 0;
   // local connections exchanged in one gather + one scatter launch (AGX_HALO_BATCH=0: a
   // launch pair per connection).  Legal when no slice reads a cell another connection's
   // insert writes (checked at agx_setup_finalize); tables per halo selector in device memory
@@ -420,9 +431,12 @@ int check_device_error(agx_ctx* c) {
     hipMemsetAsync(c->err_dev, 0, sizeof(int), c->stream);
     if (code == 3)
       return fail("Singular matrix in Gauss-Jordan elimination!");   // matrix.cpp:81
-    if (code == 2)
+    if (code == 2) {
+      c->pipe_nblocks = 0;   // (the progress words of an abandoned launch: set up afresh)
       return fail("LU-SGS pipeline: a k-plane waited beyond the spin limit for its "
-                  "predecessor (AGX_LUSGS=plane selects the launch-per-hyperplane form)");
+                  "predecessor (AGX_LUSGS=plane / AGX_SWEEP_PIPE=0 select the "
+                  "launch-per-hyperplane forms)");
+    }
     return fail("a boundary-condition variant outside this build's coverage was requested");
   }
   return 0;
@@ -703,7 +717,8 @@ static void drop_sweep_graphs_all(agx_ctx* c) {
   for (auto& g1 : c->sweep_graph_all) for (auto& g2 : g1) for (auto& g3 : g2)
     if (g3) { hipGraphExecDestroy(g3); g3 = nullptr; }
 }
-static int lusgs_sweep_all_one_launch(agx_ctx* c, bool forward, int full) {
+// the device copy of the blocks' descriptors, for kernels that serve all blocks in one launch
+static int sync_blocks_tab(agx_ctx* c) {
   const size_t nb = c->blocks.size();
   if (c->blocks_tab && c->blocks_tab_n != nb) {      // (blocks were added since)
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -729,6 +744,95 @@ static int lusgs_sweep_all_one_launch(agx_ctx* c, bool forward, int full) {
     HIPCHK(hipMemcpyAsync(c->blocks_tab, c->blocks_tab_host, sizeof(BlockDev) * nb,
                           hipMemcpyHostToDevice, c->stream));
   }
+  return 0;
+}
+// Pipelined half sweep of all blocks (k_lusgs_pipe): applicable to blocks on the cell-major
+// records (the 7-equation and block-matrix builds; the 5-equation scalar solver has its own
+// diagonal-ordered pipeline, k_lusgs_kp)
+static bool pipe_sweep_applicable(const agx_ctx* c) {
+  if (!c->sweep_pipe || c->blocks.empty()) return false;
+  for (auto& blk : c->blocks)
+    if (blk.d.d2.base || !blk.d.sw_geo) return false;
+  return true;
+}
+static void pipe_free(agx_ctx* c) {
+  for (auto& p : c->pipe_jobs) { if (p) hipFree(p); p = nullptr; }
+  if (c->pipe_slot0) hipFree(c->pipe_slot0);
+  if (c->pipe_progress) hipFree(c->pipe_progress);
+  if (c->pipe_ticket) hipFree(c->pipe_ticket);
+  c->pipe_slot0 = nullptr; c->pipe_progress = nullptr; c->pipe_ticket = nullptr;
+  c->pipe_nblocks = 0; c->pipe_njobs = 0; c->pipe_launches = 0;
+}
+static int pipe_setup(agx_ctx* c) {
+  const size_t nb = c->blocks.size();
+  HIPCHK(hipStreamSynchronize(c->stream));
+  pipe_free(c);
+  // pipeline order: plane k of every block before plane k + 1 of any (going back: from the top)
+  std::vector<PipeJob> fwd, bwd;
+  std::vector<int> slot0(nb);
+  int nk_max = 0, slots = 0, diag = 1;
+  c->pipe_maxsteps = 0;
+  for (size_t n = 0; n < nb; ++n) {
+    const BlockDev& b = c->blocks[n].d;
+    slot0[n] = slots;
+    slots += b.nk;
+    nk_max = std::max(nk_max, b.nk);
+    c->pipe_maxsteps = std::max(c->pipe_maxsteps, b.ni + b.nj - 1);
+    diag = std::max(diag, std::min(b.ni, b.nj));
+  }
+  for (int k = 0; k < nk_max; ++k)
+    for (size_t n = 0; n < nb; ++n) {
+      const int nk = c->blocks[n].d.nk;
+      if (k < nk) { fwd.push_back({(int)n, k}); bwd.push_back({(int)n, nk - 1 - k}); }
+    }
+  c->pipe_njobs = (int)fwd.size();
+  c->pipe_waves = std::max(1, std::min(8, (diag + PL3_CELLS - 1) / PL3_CELLS));
+  for (int dir = 0; dir < 2; ++dir) {
+    HIPCHK(hipMalloc((void**)&c->pipe_jobs[dir], sizeof(PipeJob) * fwd.size()));
+    HIPCHK(hipMemcpy(c->pipe_jobs[dir], (dir ? fwd : bwd).data(), sizeof(PipeJob) * fwd.size(),
+                     hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMalloc((void**)&c->pipe_slot0, sizeof(int) * nb));
+  HIPCHK(hipMemcpy(c->pipe_slot0, slot0.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&c->pipe_progress, sizeof(long long) * 16 * slots));
+  HIPCHK(hipMemset(c->pipe_progress, 0, sizeof(long long) * 16 * slots));
+  HIPCHK(hipMalloc((void**)&c->pipe_ticket, 128));
+  HIPCHK(hipMemset(c->pipe_ticket, 0, 128));
+  c->pipe_nblocks = nb;
+  return 0;
+}
+static int lusgs_sweep_pipe(agx_ctx* c, bool forward, int full) {
+  const size_t nb = c->blocks.size();
+  bool same = c->pipe_nblocks == nb;
+  if (same) {
+    int slots = 0, steps = 0;
+    for (auto& blk : c->blocks) { slots += blk.d.nk; steps = std::max(steps, blk.d.ni + blk.d.nj - 1); }
+    same = slots == c->pipe_njobs && steps == c->pipe_maxsteps;
+  }
+  if (!same && pipe_setup(c)) return 1;
+  if (sync_blocks_tab(c)) return 1;
+  PipeArgs pa;
+  pa.jobs = c->pipe_jobs[forward ? 1 : 0];
+  pa.slot0 = c->pipe_slot0;
+  pa.progress = c->pipe_progress;
+  pa.ticket = c->pipe_ticket;
+  pa.base = c->pipe_launches * (long long)(c->pipe_maxsteps + 1);
+  pa.tbase = (unsigned long long)c->pipe_launches * (unsigned long long)c->pipe_njobs;
+  pa.njobs = c->pipe_njobs;
+  pa.spin_limit = c->spin_limit;
+  pa.err = c->err_dev;
+  ++c->pipe_launches;
+  const dim3 tb(64, c->pipe_waves), grid((unsigned)c->pipe_njobs);
+  if (forward)
+    hipLaunchKernelGGL((k_lusgs_pipe<true>), grid, tb, 0, c->stream, c->blocks_tab, c->gas, c->sp, full, pa);
+  else
+    hipLaunchKernelGGL((k_lusgs_pipe<false>), grid, tb, 0, c->stream, c->blocks_tab, c->gas, c->sp, full, pa);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int lusgs_sweep_all_one_launch(agx_ctx* c, bool forward, int full) {
+  const size_t nb = c->blocks.size();
+  if (sync_blocks_tab(c)) return 1;
   int steps = 0;
   unsigned gx = 1, gy = 1;
   bool three = c->sweep_three;
@@ -1013,6 +1117,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_SPIN_LIMIT")) c->spin_limit = std::max(1, atoi(w));
     if (const char* w = getenv("AGX_GRAPHS")) c->use_graphs = atoi(w) != 0;
     if (const char* w = getenv("AGX_SWEEP_ALL")) c->sweep_all_launch = atoi(w) != 0;
+    if (const char* w = getenv("AGX_SWEEP_PIPE")) c->sweep_pipe = atoi(w) != 0;
     if (const char* w = getenv("AGX_SWEEP_THREE")) c->sweep_three = atoi(w) != 0;
     if (const char* w = getenv("AGX_SWEEP_RECORDS")) c->sweep_records = atoi(w) != 0;
     if (const char* w = getenv("AGX_MRESID_SPLIT")) c->mresid_split = std::min(64, std::max(1, atoi(w)));
@@ -1063,6 +1168,8 @@ void agx_ctx_destroy(agx_ctx* c) {
   if (c->err_host) hipHostFree(c->err_host);
   if (c->halo_buf) hipFree(c->halo_buf);
   if (c->stage_buf) hipFree(c->stage_buf);
+  if (c->rans_rec) hipFree(c->rans_rec);
+  pipe_free(c);
   for (auto& r : c->remote) {
     if (r.send) hipFree(r.send);
     if (r.recv) hipFree(r.recv);
@@ -1898,9 +2005,36 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
     for (auto& blk : c->blocks)
 #if AGX_NEQ == 7
       {
-        hipLaunchKernelGGL(k_visc_residual_rans, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
-                           0, c->stream, blk.d, c->gas, c->sp, cfl,
-                           c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH ? 1 : 0);
+        const int fourth = c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH ? 1 : 0;
+        const BlockDev& vb = blk.d;
+        if (c->visc_gather) {
+          hipLaunchKernelGGL(k_visc_residual_rans, cell_grid(vb, CELL_BLOCK), CELL_BLOCK,
+                             0, c->stream, vb, c->gas, c->sp, cfl, fourth);
+          continue;
+        }
+        // face-once form: every face evaluated by one thread, records through memory (the
+        // blocks run one after the other on the stream and share the record buffer)
+        RansRec rec;
+        rec.ni1 = vb.ni + 1; rec.nj1 = vb.nj + 1;
+        rec.nf = (long)rec.ni1 * rec.nj1 * (vb.nk + 1);
+        const size_t need = (size_t)3 * RANS_REC * rec.nf;
+        if (need > c->rans_rec_cap) {
+          HIPCHK(hipStreamSynchronize(c->stream));
+          if (c->rans_rec) HIPCHK(hipFree(c->rans_rec));
+          c->rans_rec = nullptr; c->rans_rec_cap = 0;
+          HIPCHK(hipMalloc((void**)&c->rans_rec, sizeof(double) * need));
+          c->rans_rec_cap = need;
+        }
+        rec.p = c->rans_rec;
+        const dim3 tb = CELL_BLOCK;
+        auto fgrid = [&](int di, int dj, int dk) {
+          return dim3((vb.ni + di + tb.x - 1) / tb.x, (vb.nj + dj + tb.y - 1) / tb.y, vb.nk + dk);
+        };
+        hipLaunchKernelGGL(k_rans_faces<0>, fgrid(1, 0, 0), tb, 0, c->stream, vb, c->gas, fourth, rec);
+        hipLaunchKernelGGL(k_rans_faces<1>, fgrid(0, 1, 0), tb, 0, c->stream, vb, c->gas, fourth, rec);
+        hipLaunchKernelGGL(k_rans_faces<2>, fgrid(0, 0, 1), tb, 0, c->stream, vb, c->gas, fourth, rec);
+        hipLaunchKernelGGL(k_rans_cells, cell_grid(vb, tb), tb, 0, c->stream, vb, c->gas, c->sp,
+                           cfl, fourth, rec);
       }
 #else
       if (!AGX_FAST || c->visc_gather || c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH) {
@@ -1993,6 +2127,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
   bool swept = false;
+  if (is_lusgs_solver(c) && pipe_sweep_applicable(c)) return lusgs_sweep_pipe(c, true, full);
   if (is_lusgs_solver(c) && plane_sweep_all_applicable(c)) return lusgs_sweep_all(c, true, full);
   for (auto& blk : c->blocks) {
     BlockDev& b = blk.d;
@@ -2019,6 +2154,7 @@ int agx_phase_relax_backward(agx_ctx* c, int sweep) {
   if (!is_lusgs_solver(c)) return 0;
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
+  if (pipe_sweep_applicable(c)) return lusgs_sweep_pipe(c, false, full);
   if (plane_sweep_all_applicable(c)) return lusgs_sweep_all(c, false, full);
   for (auto& blk : c->blocks) {
     if (lusgs_sweep(c, blk, false, full)) return 1;

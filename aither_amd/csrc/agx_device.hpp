@@ -589,39 +589,48 @@ __device__ inline void tsl_jacobian(const GasDev& g, const double* s, double lam
   }
   const double fac = left ? -1.0 : 1.0;
   const double third = 1.0 / 3.0;
-  double T[AGX_NJ], P[AGX_NJ];
-#pragma unroll
-  for (int q = 0; q < AGX_NJ; ++q) { T[q] = 0.0; P[q] = 0.0; }
-  T[AGX_NF * 4] = -k * t / (mu * rho) + 0.0;
+  // T (the thin-shear-layer matrix in primitive variables) has entries in its velocity block
+  // and its last row only, P = d(primitive)/d(conservative) in its first column, its diagonal
+  // and its last row: the product MatrixMultiply (matrix.cpp:193-207) forms with 125
+  // multiply-adds is written out on the 35 that are not products with a structural zero, in
+  // the same order of summation (c ascending), so the result is the same number.
+  const double sc = area[3] * mu / dist;
+  double Tv[3][3], T4[AGX_NF];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-      T[AGX_NF * (1 + r) + 1 + c] = third * n[c] * n[r] + (r == c ? 1.0 : 0.0);
-    T[AGX_NF * 4 + 1 + c] = fac * 0.5 * dist / mu * tau[c] + third * n[c] * vn + s[1 + c];
+    for (int r = 0; r < 3; ++r) Tv[r][c] = (third * n[c] * n[r] + (r == c ? 1.0 : 0.0)) * sc;
+    T4[1 + c] = (fac * 0.5 * dist / mu * tau[c] + third * n[c] * vn + s[1 + c]) * sc;
   }
-  T[AGX_NF * 4 + 4] = k / (mu * rho);
-  const double sc = area[3] * mu / dist;
-#pragma unroll
-  for (int q = 0; q < AGX_NJ; ++q) T[q] *= sc;
+  T4[0] = (-k * t / (mu * rho) + 0.0) * sc;
+  T4[4] = (k / (mu * rho)) * sc;
   const double gm1 = g.gamma - 1.0, ir = 1.0 / rho;
-  P[0] = 1.0;
+  double Pq0[3], P4q[3];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    P[AGX_NF * (1 + q)] = -ir * s[1 + q];
-    P[AGX_NF * (1 + q) + 1 + q] = ir;
-    P[AGX_NF * 4 + 1 + q] = -gm1 * s[1 + q];
-  }
-  P[AGX_NF * 4] = 0.5 * gm1 * dot3(s + 1, s + 1);
-  P[AGX_NF * 4 + 4] = gm1;
+  for (int q = 0; q < 3; ++q) { Pq0[q] = -ir * s[1 + q]; P4q[q] = -gm1 * s[1 + q]; }
+  const double P40 = 0.5 * gm1 * dot3(s + 1, s + 1), P44 = gm1;
 #pragma unroll
   for (int q = 0; q < AGX_NJ; ++q) J[q] = 0.0;
 #pragma unroll
-  for (int c = 0; c < AGX_NF; ++c)          // MatrixMultiply matrix.cpp:193-207
+  for (int r = 0; r < 3; ++r) {
+    double a = 0.0;
 #pragma unroll
-    for (int r = 0; r < AGX_NF; ++r)
+    for (int c = 0; c < 3; ++c) {
+      a = fma(Tv[r][c], Pq0[c], a);
+      J[AGX_NF * (1 + r) + 1 + c] = Tv[r][c] * ir;
+    }
+    J[AGX_NF * (1 + r)] = a;
+  }
+  {
+    double a = T4[0] * 1.0;
 #pragma unroll
-      for (int i = 0; i < AGX_NF; ++i) J[AGX_NF * r + i] += T[AGX_NF * r + c] * P[AGX_NF * c + i];
+    for (int c = 0; c < 3; ++c) {
+      a = fma(T4[1 + c], Pq0[c], a);
+      J[AGX_NF * 4 + 1 + c] = fma(T4[4], P4q[c], T4[1 + c] * ir);
+    }
+    J[AGX_NF * 4] = fma(T4[4], P40, a);
+    J[AGX_NF * 4 + 4] = T4[4] * P44;
+  }
 }
 // MatrixInverse matrix.cpp:57-103 (Gauss-Jordan with row exchanges); m becomes its
 // inverse; returns false for a singular matrix.  Fully unrolled, so the 50 doubles

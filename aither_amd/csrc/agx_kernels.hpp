@@ -1178,6 +1178,57 @@ __device__ __forceinline__ void uvwt(const BlockDev& b, const GasDev& g, long q,
   v[0] = b.state[1][q]; v[1] = b.state[2][q]; v[2] = b.state[3][q];
   v[3] = b.state[4][q] / (rho * g.R);
 }
+// state and laminar viscosity at the lower d-face of cell index qU (cells qL|qU), the second
+// half of what the viscous flux and the thin-shear-layer Jacobian need
+__device__ __forceinline__ void visc_face_state(const BlockDev& b, const GasDev& g, int d,
+                                                long qU, bool fourth, double* sf, double& muf) {
+  const long sd = b.stride(d);
+  const long qL = qU - sd;
+  // FaceReconCentral reconstruction.hpp:315-328: coeffs = LagrangeCoeff(
+  // {wU, wD}, 1, 0, 0) = {wD, wU} / (wU + wD) and the reference forms
+  // coeffs[0] * varD + coeffs[1] * varU (the wider cell gets the larger weight)
+  if (fourth) {
+    // FaceReconCentral4th reconstruction.hpp:335-379, LagrangeCoeff(w, 3, 1, 1);
+    // state and viscosity of the four cells around the face (procBlock.cpp:1325-1346)
+    // In Newton form on the divided differences of the four cell values (as the WENO
+    // stencils, agx_device.hpp): with the face at the upper edge of cell 1,
+    //   f = u1 + w1 G12 - w1 w2 D3a - w1 w2 (w0 + w1) D4,
+    //   Gab = (ub - ua) / (wa + wb),  D3a = (G12 - G01) / (w0 + w1 + w2),
+    //   D3b = (G23 - G12) / (w1 + w2 + w3),  D4 = (D3b - D3a) / (w0 + w1 + w2 + w3)
+    // (uniform widths: -1/12, 7/12, 7/12, -1/12).  Formula 2.20's generic loops unrolled to
+    // 3.3 KB of scratch per lane in this kernel.
+    const long qs[4] = {qL - sd, qL, qU, qU + sd};
+    const double w0 = b.wid[d][qs[0]], w1 = b.wid[d][qs[1]], w2 = b.wid[d][qs[2]],
+                 w3 = b.wid[d][qs[3]];
+    const double r01 = 1.0 / (w0 + w1), r12 = 1.0 / (w1 + w2), r23 = 1.0 / (w2 + w3);
+    const double t012 = 1.0 / (w0 + w1 + w2), t123 = 1.0 / (w1 + w2 + w3);
+    const double q4 = 1.0 / ((w0 + w1) + (w2 + w3));
+    const double k3 = w1 * w2, k4 = k3 * (w0 + w1);
+    auto c4 = [&](double u0, double u1, double u2, double u3) {
+      const double g01 = (u1 - u0) * r01, g12 = (u2 - u1) * r12, g23 = (u3 - u2) * r23;
+      const double d3a = (g12 - g01) * t012, d3b = (g23 - g12) * t123;
+      return u1 + w1 * g12 - k3 * d3a - k4 * ((d3b - d3a) * q4);
+    };
+    double s4[4][AGX_NEQ], mu4[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      load5(b.state, qs[m], s4[m]);
+      mu4[m] = viscosity(g, temperature(g, s4[m]));
+    }
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) sf[e] = c4(s4[0][e], s4[1][e], s4[2][e], s4[3][e]);
+    muf = c4(mu4[0], mu4[1], mu4[2], mu4[3]);
+  } else {
+    const double wU = b.wid[d][qL], wD = b.wid[d][qU];
+    const double cD = wD / (wU + wD), cU = wU / (wU + wD);
+    double sL[AGX_NEQ], sU[AGX_NEQ];
+    load5(b.state, qL, sL);
+    load5(b.state, qU, sU);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) sf[e] = cD * sU[e] + cU * sL[e];
+    muf = cD * viscosity(g, sU[4] / (sU[0] * g.R)) + cU * viscosity(g, sL[4] / (sL[0] * g.R));
+  }
+}
 // what the viscous flux and the thin-shear-layer Jacobian need at the lower d-face of
 // cell index qU (cells qL|qU): Green-Gauss gradients, face state and viscosity
 __device__ __forceinline__ void visc_face_terms(const BlockDev& b, const GasDev& g, int d,
@@ -1234,50 +1285,7 @@ __device__ __forceinline__ void visc_face_terms(const BlockDev& b, const GasDev&
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) grad[r][c] *= inv_vol;
-  // FaceReconCentral reconstruction.hpp:315-328: coeffs = LagrangeCoeff(
-  // {wU, wD}, 1, 0, 0) = {wD, wU} / (wU + wD) and the reference forms
-  // coeffs[0] * varD + coeffs[1] * varU (the wider cell gets the larger weight)
-  if (fourth) {
-    // FaceReconCentral4th reconstruction.hpp:335-379, LagrangeCoeff(w, 3, 1, 1);
-    // state and viscosity of the four cells around the face (procBlock.cpp:1325-1346)
-    // In Newton form on the divided differences of the four cell values (as the WENO
-    // stencils, agx_device.hpp): with the face at the upper edge of cell 1,
-    //   f = u1 + w1 G12 - w1 w2 D3a - w1 w2 (w0 + w1) D4,
-    //   Gab = (ub - ua) / (wa + wb),  D3a = (G12 - G01) / (w0 + w1 + w2),
-    //   D3b = (G23 - G12) / (w1 + w2 + w3),  D4 = (D3b - D3a) / (w0 + w1 + w2 + w3)
-    // (uniform widths: -1/12, 7/12, 7/12, -1/12).  Formula 2.20's generic loops unrolled to
-    // 3.3 KB of scratch per lane in this kernel.
-    const long qs[4] = {qL - sd, qL, qU, qU + sd};
-    const double w0 = b.wid[d][qs[0]], w1 = b.wid[d][qs[1]], w2 = b.wid[d][qs[2]],
-                 w3 = b.wid[d][qs[3]];
-    const double r01 = 1.0 / (w0 + w1), r12 = 1.0 / (w1 + w2), r23 = 1.0 / (w2 + w3);
-    const double t012 = 1.0 / (w0 + w1 + w2), t123 = 1.0 / (w1 + w2 + w3);
-    const double q4 = 1.0 / ((w0 + w1) + (w2 + w3));
-    const double k3 = w1 * w2, k4 = k3 * (w0 + w1);
-    auto c4 = [&](double u0, double u1, double u2, double u3) {
-      const double g01 = (u1 - u0) * r01, g12 = (u2 - u1) * r12, g23 = (u3 - u2) * r23;
-      const double d3a = (g12 - g01) * t012, d3b = (g23 - g12) * t123;
-      return u1 + w1 * g12 - k3 * d3a - k4 * ((d3b - d3a) * q4);
-    };
-    double s4[4][AGX_NEQ], mu4[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      load5(b.state, qs[m], s4[m]);
-      mu4[m] = viscosity(g, temperature(g, s4[m]));
-    }
-#pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) sf[e] = c4(s4[0][e], s4[1][e], s4[2][e], s4[3][e]);
-    muf = c4(mu4[0], mu4[1], mu4[2], mu4[3]);
-  } else {
-    const double wU = b.wid[d][qL], wD = b.wid[d][qU];
-    const double cD = wD / (wU + wD), cU = wU / (wU + wD);
-    double sL[AGX_NEQ], sU[AGX_NEQ];
-    load5(b.state, qL, sL);
-    load5(b.state, qU, sU);
-#pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) sf[e] = cD * sU[e] + cU * sL[e];
-    muf = cD * viscosity(g, vU[3]) + cU * viscosity(g, vL[3]);
-  }
+  visc_face_state(b, g, d, qU, fourth, sf, muf);
 }
 // viscous flux * |A| through the lower d-face of cell index qU (cells qL|qU)
 __device__ __forceinline__ void visc_face(const BlockDev& b, const GasDev& g,
@@ -1516,138 +1524,182 @@ __device__ inline void turb_face_grads(const BlockDev& b, int d, long qU, double
 
 template <class B>
 __device__ inline const agx_bc_surface* get_bc_surface(const B& b, int i, int j, int k, int surf);
-__global__ void __launch_bounds__(256)
-k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= b.ni || j >= b.nj) return;
-  const long q = b.idx(i, j, k);
-  double res[AGX_NEQ];
-  load5(b.resid, q, res);
-  double sr = b.specrad[q], srt = b.specrad_t[q];
-  double diag = sp.implicit ? b.a[q] : 0.0, diag_t = sp.implicit ? b.a_t[q] : 0.0;
-  double sc[AGX_NEQ];
-  load5(b.state, q, sc);
-  const double muc = viscosity(g, temperature(g, sc));
-  const double vol = b.vol[q];
-  double vgc[9], kgc[3] = {0, 0, 0}, wgc[3] = {0, 0, 0}, mutc = 0.0, f1c = 0.0, f2c = 0.0;
-  for (int e = 0; e < 9; ++e) vgc[e] = 0.0;
-  for (int d = 0; d < 3; ++d) {
-    const long s = b.stride(d);
-    double mut_lo = 0.0, f1_lo = 0.0;
-    for (int up = 0; up < 2; ++up) {
-      const long qU = q + (up ? s : 0), qL = qU - s;
-      double grad[3][4], sf[AGX_NEQ], muf, n[4], G[9], kg[3], wg[3];
-      visc_face_terms(b, g, d, qU, fourth != 0, grad, sf, muf);
-      turb_face_grads(b, d, qU, kg, wg);
-      load_area(b, d, qU, n);
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) G[3 * r + c] = grad[r][c];
-      // wall-law boundary face (procBlock.cpp:1259-1299): the wall data stored by the
-      // viscous ghost fill give the state, the viscosities and the flux itself, unless
-      // y+ < 10 switched the face to the low-Re treatment
-      const WallVars* wl = nullptr;
-      const agx_bc_surface* ws = nullptr;
-      {
-        int fc[3] = {i, j, k};
-        fc[d] += up;
-        const int nn[3] = {b.ni, b.nj, b.nk};
-        if (b.wall_off && (fc[d] == 0 || fc[d] == nn[d])) {
-          ws = get_bc_surface(b, fc[0], fc[1], fc[2], 2 * d + (fc[d] == 0 ? 1 : 2));
-          if (ws && ws->bc_type == AGX_BC_VISCOUSWALL && ws->state.is_wall_law) {
-            const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
-            const int lo[3] = {ws->imin, ws->jmin, ws->kmin}, hi[3] = {ws->imax, ws->jmax, ws->kmax};
-            const WallVars* w = b.wallv + b.wall_off[ws - b.surf] +
-                                (long)(fc[d2] - lo[d2]) * (hi[d1] - lo[d1]) + (fc[d1] - lo[d1]);
-            if (!(w->yplus < 10.0)) wl = w;
-          }
-        }
-      }
-      double mut, f1, f2, f[AGX_NEQ];
-      if (wl) {
-        const double inv_sc = 1.0 / g.scaling;
-        f1 = 1.0; f2 = 1.0;
-        muf = wl->viscosity * inv_sc;
-        mut = wl->turb_eddy_visc * inv_sc;
-        // wallData::WallState wallData.cpp:299-313
-        sf[0] = wl->density;
-        for (int r = 0; r < 3; ++r) sf[1 + r] = ws->state.velocity[r];
-        sf[4] = wl->density * g.R * wl->temperature;
-        sf[5] = wl->tke; sf[6] = wl->sdr;
-        // viscousFlux::CalcWallLawFlux viscousFlux.cpp:214-247 (WallSigmaK / W: sigma_k1 /
-        // sigma_w1 of SST, 0 of the base class)
-        const double wsk = g.wilcox ? 0.0 : SST_SIGMA_K1, wsw = g.wilcox ? 0.0 : SST_SIGMA_W1;
-        f[0] = 0.0;
-        for (int r = 0; r < 3; ++r) f[1 + r] = wl->shear[r];
-        f[4] = dot3(wl->shear, ws->state.velocity) + wl->heat_flux;
-        f[5] = (wl->viscosity + wsk * wl->turb_eddy_visc) * dot3(kg, n);
-        f[6] = (wl->viscosity + wsw * wl->turb_eddy_visc) * dot3(wg, n);
-      } else {
-      // state.LimitTurb; wall distance at the face by the two-cell rule
-      sf[5] = fmax(sf[5], AGX_TURB_MIN);
-      sf[6] = fmax(sf[6], AGX_TURB_MIN);
-      const double wU = b.wid[d][qL], wD = b.wid[d][qU];
-      const double cD = wD / (wU + wD), cU = wU / (wU + wD);
-      double wdist = cD * b.wdist[qU] + cU * b.wdist[qL];
-      if (wdist < 0.0 && wdist > -1.0e-10) wdist = 0.0;
-      if (g.wilcox) kw_eddy_visc_blending(g, sf, G, mut, f1, f2);
-      else sst_eddy_visc_blending(g, sf, G, kg, wg, muf, wdist, mut, f1, f2);
-      // viscousFlux::CalcFlux
-      const double mu = g.scaling * muf, mt = g.scaling * mut;
-      const double lambda = -(2.0 / 3.0) * (mu + mt);
-      const double trace = grad[0][0] + grad[1][1] + grad[2][2];
-      double tau[3];
-      for (int r = 0; r < 3; ++r) {
-        const double mm = (grad[r][0] + grad[0][r]) * n[0] + (grad[r][1] + grad[1][r]) * n[1] +
-                          (grad[r][2] + grad[2][r]) * n[2];
-        tau[r] = lambda * trace * n[r] + (mu + mt) * mm;
-      }
-      const double kk = conductivity(g, temperature(g, sf)) * g.scaling;
-      const double kt = mt * g.cp / g.turb_prandtl;
-      const double tg = grad[0][3] * n[0] + grad[1][3] * n[1] + grad[2][3] * n[2];
-      // UseUnlimitedEddyVisc (Wilcox): the k / omega diffusion takes rho k / omega
-      const double mtt = g.scaling * turb_diff_visc(g, sf, mut);
-      f[0] = 0.0;
-      f[1] = tau[0]; f[2] = tau[1]; f[3] = tau[2];
-      f[4] = dot3(tau, sf + 1) + (kk + kt) * tg;
-      f[5] = (mu + turb_sigma_k(g, f1) * mtt) * dot3(kg, n);
-      f[6] = (mu + turb_sigma_w(g, f1) * mtt) * dot3(wg, n);
-      }
-      // this cell is the right cell of its lower face (+), the left of its upper (-)
-      for (int e = 0; e < AGX_NEQ; ++e) res[e] += (up ? -1.0 : 1.0) * f[e] * n[3];
-      for (int e = 0; e < 9; ++e) vgc[e] += (1.0 / 6.0) * G[e];
-      for (int r = 0; r < 3; ++r) { kgc[r] += (1.0 / 6.0) * kg[r]; wgc[r] += (1.0 / 6.0) * wg[r]; }
-      mutc += (1.0 / 6.0) * mut; f1c += (1.0 / 6.0) * f1; f2c += (1.0 / 6.0) * f2;
-      if (!up) { mut_lo = mut; f1_lo = f1; }
-      if (sp.implicit && sp.block) {
-        // thin-shear-layer Jacobian with the eddy viscosity (flow block) and
-        // turbKWSst::ViscJac (turbulence block): + for both cells of a face
-        // (procBlock.cpp:1417-1424, :1468-1475; fac of fluxJacobian.hpp:749-757)
-        const double v[3] = {b.cen[0][qU] - b.cen[0][qL], b.cen[1][qU] - b.cen[1][qL],
-                             b.cen[2][qU] - b.cen[2][qL]};
-        const double dist = dot3(v, n);
-        double J[AGX_NJ], jk, jw;
-        tsl_jacobian(g, sf, muf, n, dist, up != 0, G, J, mut);
-        for (int e = 0; e < AGX_NJ; ++e) b.am[(long)e * b.nplane + q] += up ? -J[e] : J[e];
-        turb_visc_jac(g, sf, n, muf, dist, mut, f1, jk, jw);
-        b.am_t[q] += jk;
-        b.am_t[b.nplane + q] += jw;
-      }
-    }
-    // ViscCellSpectralRadius spectralRadius.hpp:94-124 and turbKWSst::
-    // ViscousCellSpectralRadius turbulence.cpp:797-815 with the LOWER face's mut, f1
-    const double fmag = 0.5 * (b.fa[d][3][q] + b.fa[d][3][q + s]);
-    const double vsr = visc_max_term(g, sc[0]) *
-                       (g.scaling * (muc * g.inv_prandtl + mut_lo / g.turb_prandtl)) * fmag * fmag / vol;
-    sr += vsr * sp.visc_cfl_coeff;
-    diag += 2.0 * vsr;
-    const double tvsr = g.scaling * (fmag * fmag / vol) / sc[0] *
-                        (muc + turb_sigma_k(g, f1_lo) * turb_diff_visc(g, sc, mut_lo));
-    srt += tvsr * sp.visc_cfl_coeff;
-    diag_t += 2.0 * tvsr;
+
+// ---- one face of the rans viscous residual -----------------------------------------------
+// What the lower d-face of the cell (fi, fj, fk) (cells qL | qU; fi, fj, fk may be one past
+// the block in direction d) contributes: its flux times |A|, and the face quantities whose
+// mean over a cell's six faces the source terms are evaluated with (procBlock.cpp:1397-1432,
+// :1462-1475 add a sixth of each to both cells).
+struct RansFace {
+  double f[AGX_NEQ];            // viscous flux * |A|
+  double G[9], kg[3], wg[3];    // velocity, k and omega gradients
+  double mut, f1, f2;           // eddy viscosity and blending functions
+};
+constexpr int RANS_REC = (AGX_NEQ - 1) + 18;   // doubles of a stored face (f[0] = 0 is not)
+// wall-law boundary face (procBlock.cpp:1259-1299): the wall data stored by the viscous ghost
+// fill give the state, the viscosities and the flux itself, unless y+ < 10 switched the face
+// to the low-Re treatment
+__device__ inline const WallVars* rans_wall_face(const BlockDev& b, int d, int fi, int fj,
+                                                 int fk, const agx_bc_surface*& ws) {
+  const int fc[3] = {fi, fj, fk};
+  const int nn[3] = {b.ni, b.nj, b.nk};
+  ws = nullptr;
+  if (!b.wall_off || !(fc[d] == 0 || fc[d] == nn[d])) return nullptr;
+  ws = get_bc_surface(b, fc[0], fc[1], fc[2], 2 * d + (fc[d] == 0 ? 1 : 2));
+  if (!ws || ws->bc_type != AGX_BC_VISCOUSWALL || !ws->state.is_wall_law) return nullptr;
+  const int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+  const int lo[3] = {ws->imin, ws->jmin, ws->kmin}, hi[3] = {ws->imax, ws->jmax, ws->kmax};
+  const WallVars* w = b.wallv + b.wall_off[ws - b.surf] +
+                      (long)(fc[d2] - lo[d2]) * (hi[d1] - lo[d1]) + (fc[d1] - lo[d1]);
+  return w->yplus < 10.0 ? nullptr : w;
+}
+// the state and laminar viscosity the flux and the Jacobians of the face are evaluated with
+// (wallData::WallState wallData.cpp:299-313 at a wall-law face; state.LimitTurb elsewhere)
+__device__ inline void rans_face_state(const GasDev& g, const WallVars* wl,
+                                       const agx_bc_surface* ws, double* sf, double& muf) {
+  if (wl) {
+    muf = wl->viscosity * (1.0 / g.scaling);
+    sf[0] = wl->density;
+    for (int r = 0; r < 3; ++r) sf[1 + r] = ws->state.velocity[r];
+    sf[4] = wl->density * g.R * wl->temperature;
+    sf[5] = wl->tke; sf[6] = wl->sdr;
+  } else {
+    sf[5] = fmax(sf[5], AGX_TURB_MIN);
+    sf[6] = fmax(sf[6], AGX_TURB_MIN);
   }
-  // ---- source terms of the cell, turbKWSst::CalcTurbSrc turbulence.cpp:637-690 ----
+}
+__device__ inline void rans_face(const BlockDev& b, const GasDev& g, int d, int fi, int fj,
+                                 int fk, bool fourth, RansFace& o, double* sf, double& muf,
+                                 double* n) {
+  const long qU = b.idx(fi, fj, fk), qL = qU - b.stride(d);
+  double grad[3][4];
+  visc_face_terms(b, g, d, qU, fourth, grad, sf, muf);
+  turb_face_grads(b, d, qU, o.kg, o.wg);
+  load_area(b, d, qU, n);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) o.G[3 * r + c] = grad[r][c];
+  const agx_bc_surface* ws;
+  const WallVars* wl = rans_wall_face(b, d, fi, fj, fk, ws);
+  rans_face_state(g, wl, ws, sf, muf);
+  double f[AGX_NEQ];
+  if (wl) {
+    const double inv_sc = 1.0 / g.scaling;
+    o.f1 = 1.0; o.f2 = 1.0;
+    o.mut = wl->turb_eddy_visc * inv_sc;
+    // viscousFlux::CalcWallLawFlux viscousFlux.cpp:214-247 (WallSigmaK / W: sigma_k1 /
+    // sigma_w1 of SST, 0 of the base class)
+    const double wsk = g.wilcox ? 0.0 : SST_SIGMA_K1, wsw = g.wilcox ? 0.0 : SST_SIGMA_W1;
+    f[0] = 0.0;
+    for (int r = 0; r < 3; ++r) f[1 + r] = wl->shear[r];
+    f[4] = dot3(wl->shear, ws->state.velocity) + wl->heat_flux;
+    f[5] = (wl->viscosity + wsk * wl->turb_eddy_visc) * dot3(o.kg, n);
+    f[6] = (wl->viscosity + wsw * wl->turb_eddy_visc) * dot3(o.wg, n);
+  } else {
+    // wall distance at the face by the two-cell rule
+    const double wU = b.wid[d][qL], wD = b.wid[d][qU];
+    const double cD = wD / (wU + wD), cU = wU / (wU + wD);
+    double wdist = cD * b.wdist[qU] + cU * b.wdist[qL];
+    if (wdist < 0.0 && wdist > -1.0e-10) wdist = 0.0;
+    if (g.wilcox) kw_eddy_visc_blending(g, sf, o.G, o.mut, o.f1, o.f2);
+    else sst_eddy_visc_blending(g, sf, o.G, o.kg, o.wg, muf, wdist, o.mut, o.f1, o.f2);
+    // viscousFlux::CalcFlux
+    const double mu = g.scaling * muf, mt = g.scaling * o.mut;
+    const double lambda = -(2.0 / 3.0) * (mu + mt);
+    const double trace = grad[0][0] + grad[1][1] + grad[2][2];
+    double tau[3];
+    for (int r = 0; r < 3; ++r) {
+      const double mm = (grad[r][0] + grad[0][r]) * n[0] + (grad[r][1] + grad[1][r]) * n[1] +
+                        (grad[r][2] + grad[2][r]) * n[2];
+      tau[r] = lambda * trace * n[r] + (mu + mt) * mm;
+    }
+    const double kk = conductivity(g, temperature(g, sf)) * g.scaling;
+    const double kt = mt * g.cp / g.turb_prandtl;
+    const double tg = grad[0][3] * n[0] + grad[1][3] * n[1] + grad[2][3] * n[2];
+    // UseUnlimitedEddyVisc (Wilcox): the k / omega diffusion takes rho k / omega
+    const double mtt = g.scaling * turb_diff_visc(g, sf, o.mut);
+    f[0] = 0.0;
+    f[1] = tau[0]; f[2] = tau[1]; f[3] = tau[2];
+    f[4] = dot3(tau, sf + 1) + (kk + kt) * tg;
+    f[5] = (mu + turb_sigma_k(g, o.f1) * mtt) * dot3(o.kg, n);
+    f[6] = (mu + turb_sigma_w(g, o.f1) * mtt) * dot3(o.wg, n);
+  }
+  for (int e = 0; e < AGX_NEQ; ++e) o.f[e] = f[e] * n[3];
+}
+
+// ---- one cell: six faces in, residual / spectral radii / diagonal / sources out ----------
+struct RansCell {
+  double res[AGX_NEQ], sc[AGX_NEQ];
+  double sr, srt, diag, diag_t, muc, vol;
+  double vgc[9], kgc[3], wgc[3], mutc, f1c, f2c;
+  double mut_lo, f1_lo;
+};
+__device__ inline void rans_cell_begin(const BlockDev& b, const GasDev& g, const SolverDev& sp,
+                                       long q, RansCell& c) {
+  load5(b.resid, q, c.res);
+  c.sr = b.specrad[q]; c.srt = b.specrad_t[q];
+  c.diag = sp.implicit ? b.a[q] : 0.0; c.diag_t = sp.implicit ? b.a_t[q] : 0.0;
+  load5(b.state, q, c.sc);
+  c.muc = viscosity(g, temperature(g, c.sc));
+  c.vol = b.vol[q];
+  for (int e = 0; e < 9; ++e) c.vgc[e] = 0.0;
+  for (int r = 0; r < 3; ++r) { c.kgc[r] = 0.0; c.wgc[r] = 0.0; }
+  c.mutc = 0.0; c.f1c = 0.0; c.f2c = 0.0; c.mut_lo = 0.0; c.f1_lo = 0.0;
+}
+// a face joins its cell: the right cell of its lower face (+), the left of its upper (-)
+__device__ inline void rans_cell_add_face(RansCell& c, const RansFace& o, bool up) {
+  for (int e = 0; e < AGX_NEQ; ++e) c.res[e] += up ? -o.f[e] : o.f[e];
+  for (int e = 0; e < 9; ++e) c.vgc[e] += (1.0 / 6.0) * o.G[e];
+  for (int r = 0; r < 3; ++r) { c.kgc[r] += (1.0 / 6.0) * o.kg[r]; c.wgc[r] += (1.0 / 6.0) * o.wg[r]; }
+  c.mutc += (1.0 / 6.0) * o.mut; c.f1c += (1.0 / 6.0) * o.f1; c.f2c += (1.0 / 6.0) * o.f2;
+  if (!up) { c.mut_lo = o.mut; c.f1_lo = o.f1; }
+}
+// thin-shear-layer Jacobian with the eddy viscosity (flow block) and turbKWSst::ViscJac
+// (turbulence block): + for both cells of a face (procBlock.cpp:1417-1424, :1468-1475; fac of
+// fluxJacobian.hpp:749-757)
+// (D, Dt: the cell's main-diagonal blocks, held by the caller from rans_cell_jac_begin to
+// rans_cell_finish -- one load and one store per entry instead of one per face)
+__device__ inline void rans_cell_face_jacobians(const BlockDev& b, const GasDev& g, long qU,
+                                                long qL, bool up, const double* sf, double muf,
+                                                const double* n, const RansFace& o, double* D,
+                                                double* Dt) {
+  const double v[3] = {b.cen[0][qU] - b.cen[0][qL], b.cen[1][qU] - b.cen[1][qL],
+                       b.cen[2][qU] - b.cen[2][qL]};
+  const double dist = dot3(v, n);
+  double J[AGX_NJ], jk, jw;
+  tsl_jacobian(g, sf, muf, n, dist, up, o.G, J, o.mut);
+  for (int e = 0; e < AGX_NJ; ++e) D[e] += up ? -J[e] : J[e];
+  turb_visc_jac(g, sf, n, muf, dist, o.mut, o.f1, jk, jw);
+  Dt[0] += jk;
+  Dt[1] += jw;
+}
+__device__ inline void rans_cell_jac_begin(const BlockDev& b, const SolverDev& sp, long q,
+                                           double* D, double* Dt) {
+  if (!(sp.implicit && sp.block)) return;
+  for (int e = 0; e < AGX_NJ; ++e) D[e] = b.am[(long)e * b.nplane + q];
+  Dt[0] = b.am_t[q];
+  Dt[1] = b.am_t[b.nplane + q];
+}
+// ViscCellSpectralRadius spectralRadius.hpp:94-124 and turbKWSst::ViscousCellSpectralRadius
+// turbulence.cpp:797-815 with the LOWER face's mut, f1
+__device__ inline void rans_cell_direction(const BlockDev& b, const GasDev& g,
+                                           const SolverDev& sp, int d, long q, RansCell& c) {
+  const double fmag = 0.5 * (b.fa[d][3][q] + b.fa[d][3][q + b.stride(d)]);
+  const double vsr = visc_max_term(g, c.sc[0]) *
+                     (g.scaling * (c.muc * g.inv_prandtl + c.mut_lo / g.turb_prandtl)) * fmag * fmag / c.vol;
+  c.sr += vsr * sp.visc_cfl_coeff;
+  c.diag += 2.0 * vsr;
+  const double tvsr = g.scaling * (fmag * fmag / c.vol) / c.sc[0] *
+                      (c.muc + turb_sigma_k(g, c.f1_lo) * turb_diff_visc(g, c.sc, c.mut_lo));
+  c.srt += tvsr * sp.visc_cfl_coeff;
+  c.diag_t += 2.0 * tvsr;
+}
+// source terms of the cell (turbKWSst::CalcTurbSrc turbulence.cpp:637-690), then everything
+// the cell stores
+__device__ inline void rans_cell_finish(const BlockDev& b, const GasDev& g, const SolverDev& sp,
+                                        double cfl, long q, RansCell& c, double* D, double* Dt) {
+  const double* sc = c.sc;
+  const double* vgc = c.vgc;
+  const double vol = c.vol, mutc = c.mutc, f1c = c.f1c, f2c = c.f2c;
   {
     const double inv_sc = 1.0 / g.scaling;
     // turbSstDes::CalcTurbSrc turbulence.cpp:866-922: phi = max((1 - f2) Lt / (cdes width), 1)
@@ -1664,11 +1716,11 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
     const double trace = vgc[0] + vgc[4] + vgc[8];
     double ddot = 0.0;
     for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) {
-        const double id = r == c ? 1.0 : 0.0;
-        const double tau = lambda * trace * id + mutc * (vgc[3 * r + c] + vgc[3 * c + r]) -
+      for (int cc = 0; cc < 3; ++cc) {
+        const double id = r == cc ? 1.0 : 0.0;
+        const double tau = lambda * trace * id + mutc * (vgc[3 * r + cc] + vgc[3 * cc + r]) -
                            2.0 / 3.0 * sc[0] * sc[5] * id;
-        ddot += tau * vgc[3 * c + r];
+        ddot += tau * vgc[3 * cc + r];
       }
     double beta;
     if (g.wilcox) {      // turbKWWilcox::CalcTurbSrc turbulence.cpp:359-407
@@ -1676,20 +1728,20 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
       const double omg_dest = inv_sc * beta * (sc[0] * sc[6] * sc[6]);
       const double tke_prod = fmax(g.scaling * ddot, 0.0);
       const double omg_prod = fmax(0.52 * sc[6] / sc[5] * tke_prod, 0.0);
-      const double kw = dot3(kgc, wgc);
+      const double kw = dot3(c.kgc, c.wgc);
       const double omg_cd = g.scaling * (kw <= 0.0 ? 0.0 : 0.125) * (sc[0] / sc[6] * kw);
-      res[5] -= (tke_prod - tke_dest) * vol;
-      res[6] -= (omg_prod - omg_dest + omg_cd) * vol;
+      c.res[5] -= (tke_prod - tke_dest) * vol;
+      c.res[6] -= (omg_prod - omg_dest + omg_cd) * vol;
     } else {
-      const double cdkw = sst_cdkw(sc, kgc, wgc);
+      const double cdkw = sst_cdkw(sc, c.kgc, c.wgc);
       const double gam = sst_blend(SST_GAMMA1, SST_GAMMA2, f1c);
       beta = sst_blend(SST_BETA1, SST_BETA2, f1c);
       const double omg_dest = inv_sc * beta * (sc[0] * sc[6] * sc[6]);
       const double tke_prod = fmax(fmin(g.scaling * ddot, SST_KPROD2DEST * tke_dest), 0.0);
       const double omg_prod = fmax(gam * sc[0] / mutc * tke_prod, 0.0);
       const double omg_cd = g.scaling * (1.0 - f1c) * cdkw;
-      res[5] -= (tke_prod - tke_dest) * vol;
-      res[6] -= (omg_prod - omg_dest + omg_cd) * vol;
+      c.res[5] -= (tke_prod - tke_dest) * vol;
+      c.res[6] -= (omg_prod - omg_dest + omg_cd) * vol;
     }
     double src_sr = -2.0 * SST_BETA_STAR * sc[6] * vol * inv_sc;   // SrcSpecRad :739-747
     if (g.sstdes) {
@@ -1699,22 +1751,142 @@ k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth)
       const double j11 = -2.0 * SST_BETA2 * sc[6] * vol * inv_sc;
       src_sr = -1.0 * fmax(fabs(j00), fabs(j11));
     }
-    srt -= src_sr;
-    diag_t -= src_sr;
+    c.srt -= src_sr;
+    c.diag_t -= src_sr;
     if (sp.implicit && sp.block) {     // SubtractFromTurb(TurbSrcJac), turbulence.cpp:749-770
-      b.am_t[q] -= -2.0 * SST_BETA_STAR * sc[6] * phi * vol * inv_sc;
-      b.am_t[b.nplane + q] -= -2.0 * beta * sc[6] * vol * inv_sc;
+      Dt[0] -= -2.0 * SST_BETA_STAR * sc[6] * phi * vol * inv_sc;
+      Dt[1] -= -2.0 * beta * sc[6] * vol * inv_sc;
+      for (int e = 0; e < AGX_NJ; ++e) b.am[(long)e * b.nplane + q] = D[e];
+      b.am_t[q] = Dt[0];
+      b.am_t[b.nplane + q] = Dt[1];
     }
   }
-  store5(b.resid, q, res);
-  b.specrad[q] = sr;
-  b.specrad_t[q] = srt;
-  if (sp.implicit) { b.a[q] = diag; b.a_t[q] = diag_t; }
-  b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (vol / fmax(fmax(sr, srt), 0.0));
+  store5(b.resid, q, c.res);
+  b.specrad[q] = c.sr;
+  b.specrad_t[q] = c.srt;
+  if (sp.implicit) { b.a[q] = c.diag; b.a_t[q] = c.diag_t; }
+  b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (vol / fmax(fmax(c.sr, c.srt), 0.0));
   b.turb3[0][q] = mutc; b.turb3[1][q] = f1c; b.turb3[2][q] = f2c;
-  b.viscp[q] = muc;       // viscosity_ of this UpdateAuxillaryVariables, read next iteration
+  b.viscp[q] = c.muc;     // viscosity_ of this UpdateAuxillaryVariables, read next iteration
   if (sp.implicit && sp.block)     // velocityGrad_ of the cell, read by the off-diagonal terms
     for (int e = 0; e < 9; ++e) b.vg[(long)e * b.nplane + q] = vgc[e];
+}
+
+// Gather form: one thread per cell evaluates its six faces (every face twice).  Kept as the
+// form the face-once kernels below are tested against (AGX_RANS_VISC=gather).
+__global__ void __launch_bounds__(256)
+k_visc_residual_rans(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  RansCell c;
+  double D[AGX_NJ], Dt[2];
+  rans_cell_begin(b, g, sp, q, c);
+  rans_cell_jac_begin(b, sp, q, D, Dt);
+  for (int d = 0; d < 3; ++d) {
+    const long s = b.stride(d);
+    for (int up = 0; up < 2; ++up) {
+      int fc[3] = {i, j, k};
+      fc[d] += up;
+      RansFace o;
+      double sf[AGX_NEQ], muf, n[4];
+      rans_face(b, g, d, fc[0], fc[1], fc[2], fourth != 0, o, sf, muf, n);
+      rans_cell_add_face(c, o, up != 0);
+      if (sp.implicit && sp.block) {
+        const long qU = q + (up ? s : 0);
+        rans_cell_face_jacobians(b, g, qU, qU - s, up != 0, sf, muf, n, o, D, Dt);
+      }
+    }
+    rans_cell_direction(b, g, sp, d, q, c);
+  }
+  rans_cell_finish(b, g, sp, cfl, q, c, D, Dt);
+}
+
+// Face-once form (production).  k_rans_faces<D> evaluates every d-face of the block once --
+// one thread per face, the ten-cell gradient stencils, pow / tanh of the blending functions
+// and the flux -- and stores RANS_REC doubles per face on the lattice of (ni+1)(nj+1)(nk+1)
+// points, one plane per quantity; k_rans_cells reads the six records of a cell and does
+// what is left: the sums, the Jacobians of the block solvers (from the stored gradients and
+// eddy viscosity; the face state is formed again, two cells), spectral radii, sources.  The
+// gather form evaluates each face twice inside one 7-equation thread with six faces' live
+// ranges; this one trades that for 3 x RANS_REC doubles per cell through memory.
+struct RansRec {
+  double* p;      // 3 x RANS_REC planes of nf doubles
+  long nf;        // lattice points
+  int ni1, nj1;   // lattice extents in i, j
+  __device__ long at(int i, int j, int k) const { return ((long)k * nj1 + j) * ni1 + i; }
+  __device__ double* plane(int d, int v) const { return p + ((long)d * RANS_REC + v) * nf; }
+};
+#ifndef RANS_FACES_WAVES
+#define RANS_FACES_WAVES 1
+#endif
+#ifndef RANS_CELLS_WAVES
+#define RANS_CELLS_WAVES 1
+#endif
+template <int D>
+__global__ void __launch_bounds__(256, RANS_FACES_WAVES)
+k_rans_faces(BlockDev b, GasDev g, int fourth, RansRec rec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni + (D == 0) || j >= b.nj + (D == 1) || k >= b.nk + (D == 2)) return;
+  RansFace o;
+  double sf[AGX_NEQ], muf, n[4];
+  rans_face(b, g, D, i, j, k, fourth != 0, o, sf, muf, n);
+  const long at = rec.at(i, j, k);
+  int v = 0;
+  for (int e = 1; e < AGX_NEQ; ++e) rec.plane(D, v++)[at] = o.f[e];
+  for (int e = 0; e < 9; ++e) rec.plane(D, v++)[at] = o.G[e];
+  for (int r = 0; r < 3; ++r) rec.plane(D, v++)[at] = o.kg[r];
+  for (int r = 0; r < 3; ++r) rec.plane(D, v++)[at] = o.wg[r];
+  rec.plane(D, v++)[at] = o.mut;
+  rec.plane(D, v++)[at] = o.f1;
+  rec.plane(D, v++)[at] = o.f2;
+}
+__global__ void __launch_bounds__(256, RANS_CELLS_WAVES)
+k_rans_cells(BlockDev b, GasDev g, SolverDev sp, double cfl, int fourth, RansRec rec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  RansCell c;
+  double D[AGX_NJ], Dt[2];
+  rans_cell_begin(b, g, sp, q, c);
+  rans_cell_jac_begin(b, sp, q, D, Dt);
+  for (int d = 0; d < 3; ++d) {
+    const long s = b.stride(d);
+    for (int up = 0; up < 2; ++up) {
+      int fc[3] = {i, j, k};
+      fc[d] += up;
+      const long at = rec.at(fc[0], fc[1], fc[2]);
+      RansFace o;
+      int v = 0;
+      o.f[0] = 0.0;
+      for (int e = 1; e < AGX_NEQ; ++e) o.f[e] = rec.plane(d, v++)[at];
+      for (int e = 0; e < 9; ++e) o.G[e] = rec.plane(d, v++)[at];
+      for (int r = 0; r < 3; ++r) o.kg[r] = rec.plane(d, v++)[at];
+      for (int r = 0; r < 3; ++r) o.wg[r] = rec.plane(d, v++)[at];
+      o.mut = rec.plane(d, v++)[at];
+      o.f1 = rec.plane(d, v++)[at];
+      o.f2 = rec.plane(d, v++)[at];
+      rans_cell_add_face(c, o, up != 0);
+      if (sp.implicit && sp.block) {
+        const long qU = q + (up ? s : 0);
+        double sf[AGX_NEQ], muf, n[4];
+        visc_face_state(b, g, d, qU, fourth != 0, sf, muf);
+        const agx_bc_surface* ws;
+        const WallVars* wl = rans_wall_face(b, d, fc[0], fc[1], fc[2], ws);
+        rans_face_state(g, wl, ws, sf, muf);
+        load_area(b, d, qU, n);
+        rans_cell_face_jacobians(b, g, qU, qU - s, up != 0, sf, muf, n, o, D, Dt);
+      }
+    }
+    rans_cell_direction(b, g, sp, d, q, c);
+  }
+  rans_cell_finish(b, g, sp, cfl, q, c, D, Dt);
 }
 #endif  // AGX_NEQ == 7
 
@@ -2405,6 +2577,9 @@ __global__ void __launch_bounds__(256) k_sweep_records(BlockDev b, SolverDev sp)
 // one direction of add_off_diag, from the records (identical arithmetic): the
 // off-diagonal term of the lower / upper d-neighbour of cell q into od; false: the
 // neighbour does not count (physical boundary)
+// (COH: x is read with agent-scope loads that pass the caches -- the pipelined form, where
+// it was written by another workgroup of the same launch)
+template <bool COH = false>
 __device__ __forceinline__ bool off_diag_rec_dir(const BlockDev& b, const GasDev& g,
                                                  const SolverDev& sp, int i, int j, int k,
                                                  long q, bool lower, int d, double* od) {
@@ -2428,7 +2603,11 @@ __device__ __forceinline__ bool off_diag_rec_dir(const BlockDev& b, const GasDev
 #pragma unroll
   for (int e = 0; e < 4; ++e) area[e] = gf[3 + 4 * d + e];
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) { sn[e] = dn[e]; du[e] = dn[SW_X + e]; }
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    sn[e] = dn[e];
+    du[e] = COH ? __hip_atomic_load(dn + SW_X + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                : dn[SW_X + e];
+  }
   double dist = 1.0, mu = 0.0;
   if (sp.viscous) {
     const double v[3] = {lower ? gq[0] - gn[0] : gn[0] - gq[0],
@@ -2648,15 +2827,11 @@ __global__ void __launch_bounds__(256) k_lusgs_plane(BlockDev b, GasDev g, Solve
 // one-lane form (lower i, j, k, then upper i, j, k), applies the inverse and stores.
 // 21 cells per wave row (lane 63 idles): grid.x = ceil(nj / 21).
 constexpr int PL3_CELLS = 21;
-template <bool FORWARD>
-__device__ __forceinline__ void lusgs_plane_cell3(const BlockDev& b, const GasDev& g,
-                                                  const SolverDev& sp, int plane, int full) {
-  const int lane = threadIdx.x;
-  const int c = lane / 3, d = lane - 3 * c;
-  const int j = blockIdx.x * PL3_CELLS + c;
-  const int k = blockIdx.y * blockDim.y + threadIdx.y;
-  const int i = plane - j - k;
-  const bool active = c < PL3_CELLS && j < b.nj && k < b.nk && i >= 0 && i < b.ni;
+// lane d of the three lanes of cell (i, j, k); inactive lanes only take part in the shuffles
+template <bool FORWARD, bool COH>
+__device__ __forceinline__ void lusgs_cell3(const BlockDev& b, const GasDev& g,
+                                            const SolverDev& sp, int i, int j, int k,
+                                            bool active, int d, int full) {
   const long q = active ? b.idx(i, j, k) : 0;
   // first the side the sweep comes from, then (both triangles) the other one
   double v1[AGX_NEQ], v2[AGX_NEQ];
@@ -2664,11 +2839,11 @@ __device__ __forceinline__ void lusgs_plane_cell3(const BlockDev& b, const GasDe
   for (int e = 0; e < AGX_NEQ; ++e) { v1[e] = 0.0; v2[e] = 0.0; }
   if (active) {
     double od[AGX_NEQ];
-    if (off_diag_rec_dir(b, g, sp, i, j, k, q, FORWARD, d, od)) {
+    if (off_diag_rec_dir<COH>(b, g, sp, i, j, k, q, FORWARD, d, od)) {
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e) v1[e] = (FORWARD ? 1.0 : -1.0) * od[e];
     }
-    if (full && off_diag_rec_dir(b, g, sp, i, j, k, q, !FORWARD, d, od)) {
+    if (full && off_diag_rec_dir<COH>(b, g, sp, i, j, k, q, !FORWARD, d, od)) {
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e) v2[e] = (FORWARD ? -1.0 : 1.0) * od[e];
     }
@@ -2688,6 +2863,7 @@ __device__ __forceinline__ void lusgs_plane_cell3(const BlockDev& b, const GasDe
   }
   if (!active || d != 0) return;
   double out[AGX_NEQ];
+  double* xq = b.sw_dyn + q * SW_DYN + SW_X;
   if (FORWARD || full) {
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) acc[e] = b.sw_rhs[q * SW_RHS + e] + acc[e];
@@ -2695,14 +2871,29 @@ __device__ __forceinline__ void lusgs_plane_cell3(const BlockDev& b, const GasDe
   } else {
     double xo[AGX_NEQ];
 #pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) xo[e] = b.sw_dyn[q * SW_DYN + SW_X + e];
+    for (int e = 0; e < AGX_NEQ; ++e)
+      xo[e] = COH ? __hip_atomic_load(xq + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : xq[e];
     apply_ainv(b, sp, q, acc, out);     // acc = -U
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) out[e] = xo[e] + out[e];
   }
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) b.sw_dyn[q * SW_DYN + SW_X + e] = out[e];
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    if (COH) __hip_atomic_store(xq + e, out[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else xq[e] = out[e];
+  }
   store5(b.x, q, out);
+}
+template <bool FORWARD>
+__device__ __forceinline__ void lusgs_plane_cell3(const BlockDev& b, const GasDev& g,
+                                                  const SolverDev& sp, int plane, int full) {
+  const int lane = threadIdx.x;
+  const int c = lane / 3, d = lane - 3 * c;
+  const int j = blockIdx.x * PL3_CELLS + c;
+  const int k = blockIdx.y * blockDim.y + threadIdx.y;
+  const int i = plane - j - k;
+  const bool active = c < PL3_CELLS && j < b.nj && k < b.nk && i >= 0 && i < b.ni;
+  lusgs_cell3<FORWARD, false>(b, g, sp, i, j, k, active, d, full);
 }
 template <bool FORWARD>
 __global__ void __launch_bounds__(256) k_lusgs_plane3(BlockDev b, GasDev g, SolverDev sp, int plane, int full) {
@@ -2727,6 +2918,89 @@ k_lusgs_plane_all(const BlockDev* tab, GasDev g, SolverDev sp, int t, int full) 
   const int nplanes = b.ni + b.nj + b.nk - 2;
   if (t >= nplanes) return;
   lusgs_plane_cell<FORWARD>(b, g, sp, FORWARD ? t : nplanes - 1 - t, full);
+}
+
+
+// ---------------------------------------------------------------------------
+// The same half sweep as ONE launch: a workgroup per k-plane of every block, marching the
+// anti-diagonals s = i + j of its plane -- cell (i, j, k) is step s of plane k, which is
+// hyperplane order: its in-plane neighbours are the workgroup's own previous step, the third
+// one is step s of the plane below (above, going back), finished by that plane's workgroup.
+// The planes of a block therefore run as a pipeline one step apart; a rank's blocks side by
+// side (4 x 64 planes = 256 workgroups for BASELINE configs[4]).  Every cell gets the x of
+// exactly the neighbours the plane-per-launch forms give it: bit-identical results
+// (test_plane_sweep_forms_agree_bitwise), 636 launches of ~13 us less per sweep pair.
+//   * x is written with agent-scope (write-through) stores and read with agent-scope loads;
+//     what else a cell reads does not change during the launch.
+//   * hand-off between planes: a workgroup waits for its stores' acknowledgement, passes a
+//     barrier and publishes "step t done" in its plane's progress word (a 128-byte line of
+//     its own); the plane above polls that word.  Progress values and tickets only grow
+//     (launch serial x steps), so nothing is reset between launches.
+//   * planes are handed out by ticket in pipeline order: a plane's predecessor has a lower
+//     ticket, so it is running or done whatever the dispatch order; a wait longer than
+//     AGX_SPIN_LIMIT polls raises the error flag and every workgroup leaves.
+struct PipeJob { int block, k; };
+struct PipeArgs {
+  const PipeJob* jobs;      // pipeline order of this direction
+  const int* slot0;         // per block: progress slot of its plane 0
+  long long* progress;      // 16 words per slot
+  unsigned long long* ticket;
+  long long base;           // progress of step t of this launch: base + t + 1
+  unsigned long long tbase; // first ticket of this launch
+  int njobs, spin_limit;
+  int* err;
+};
+template <bool FORWARD>
+__global__ void __launch_bounds__(512)
+k_lusgs_pipe(const BlockDev* tab, GasDev g, SolverDev sp, int full, PipeArgs pa) {
+  __shared__ int s_job, s_bad;
+  const int lane = threadIdx.x, wv = threadIdx.y, nw = blockDim.y;
+  if (lane == 0 && wv == 0) {
+    s_job = (int)(atomicAdd(pa.ticket, 1ULL) - pa.tbase);
+    s_bad = 0;
+  }
+  __syncthreads();
+  const int job = s_job;
+  if (job < 0 || job >= pa.njobs) return;
+  const PipeJob jb = pa.jobs[job];
+  const BlockDev& b = tab[jb.block];
+  const int k = jb.k, kp = FORWARD ? k - 1 : k + 1;
+  const bool has_pred = kp >= 0 && kp < b.nk;
+  const long long* ppred = pa.progress + (long)(pa.slot0[jb.block] + (has_pred ? kp : k)) * 16;
+  long long* pown = pa.progress + (long)(pa.slot0[jb.block] + k) * 16;
+  const int nsteps = b.ni + b.nj - 1;
+  const int c = lane / 3, d = lane - 3 * c;
+  for (int t = 0; t < nsteps; ++t) {
+    const int s = FORWARD ? t : nsteps - 1 - t;
+    bool ok = true;
+    if (has_pred) {
+      int spins = 0;
+      while (__hip_atomic_load(ppred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pa.base + t + 1) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > pa.spin_limit ||
+            ((spins & 63) == 0 &&
+             __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          ok = false;
+          break;
+        }
+      }
+    }
+    if (ok) {
+      const int ilo = max(0, s - (b.nj - 1)), ncell = min(b.ni - 1, s) - ilo + 1;
+      for (int c0 = wv * PL3_CELLS; c0 < ncell; c0 += nw * PL3_CELLS) {
+        const int i = ilo + c0 + c;
+        lusgs_cell3<FORWARD, true>(b, g, sp, i, s - i, k, c < PL3_CELLS && c0 + c < ncell, d, full);
+      }
+    } else {
+      s_bad = 1;
+      __hip_atomic_store(pa.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // this wave's stores of x have been acknowledged
+    __syncthreads();
+    if (s_bad) return;
+    if (lane == 0 && wv == 0)
+      __hip_atomic_store(pown, pa.base + t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 }  // namespace agx

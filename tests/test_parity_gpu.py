@@ -774,16 +774,19 @@ def test_walllaw_refused_by_the_five_equation_library(agx):
 
 @pytest.mark.gpu
 def test_plane_sweep_forms_agree_bitwise(agx_rans):
-    """The hyperplane-by-hyperplane sweeps of the 7-equation / block-matrix builds: all
-    blocks of a step in one launch reading cell-major records with three lanes per cell
-    (default), one lane per cell (AGX_SWEEP_THREE=0), one graph per block on branch
+    """The hyperplane sweeps of the 7-equation / block-matrix builds: ONE launch per half
+    sweep with a workgroup per k-plane, pipelined (k_lusgs_pipe, default), and with
+    AGX_SWEEP_PIPE=0 a launch per hyperplane -- all blocks of a step in one launch reading
+    cell-major records with three lanes per cell, one lane per cell (AGX_SWEEP_THREE=0), one graph per block on branch
     streams (AGX_SWEEP_ALL=0), plane-major loads (AGX_SWEEP_RECORDS=0) and launches
     without graphs (AGX_GRAPHS=0) are the same arithmetic in a different order of memory
     accesses: bit-identical states on the reference's wallLaw case
     (two blocks, BLU-SGS with four sweeps, wall functions)."""
     ref = None
-    for env in ({}, {"AGX_SWEEP_ALL": "0"}, {"AGX_SWEEP_RECORDS": "0"}, {"AGX_GRAPHS": "0"},
-                {"AGX_SWEEP_THREE": "0"}, {"AGX_SWEEP_THREE": "0", "AGX_SWEEP_ALL": "0"},
+    off = {"AGX_SWEEP_PIPE": "0"}
+    for env in ({}, off, {**off, "AGX_SWEEP_ALL": "0"}, {"AGX_SWEEP_RECORDS": "0"},
+                {**off, "AGX_GRAPHS": "0"}, {**off, "AGX_SWEEP_THREE": "0"},
+                {**off, "AGX_SWEEP_THREE": "0", "AGX_SWEEP_ALL": "0"},
                 {"AGX_SWEEP_ALL": "0", "AGX_SWEEP_RECORDS": "0"}):
         got = _run_with_env(agx_rans, golden_case("wallLaw"), 3, env)
         if ref is None:
@@ -792,11 +795,49 @@ def test_plane_sweep_forms_agree_bitwise(agx_rans):
 
 
 @pytest.mark.gpu
+def test_pipelined_sweep_spin_limit_error_path_and_recovery(agx_rans):
+    """k_lusgs_pipe: a k-plane that polls longer than AGX_SPIN_LIMIT for the plane below
+    raises the error flag, every workgroup leaves, agx_iterate returns the error; the SAME
+    context then sets its pipeline up afresh -- with a sane limit a fresh context gives the
+    states of the launch-per-hyperplane form (wallLaw: two blocks, BLU-SGS)."""
+    old = os.environ.get("AGX_SPIN_LIMIT")
+    os.environ["AGX_SPIN_LIMIT"] = "1"
+    try:
+        s = Solver(agx_rans, golden_case("wallLaw"))
+    finally:
+        if old is None:
+            os.environ.pop("AGX_SPIN_LIMIT", None)
+        else:
+            os.environ["AGX_SPIN_LIMIT"] = old
+    with pytest.raises(RuntimeError, match="spin limit"):
+        for nn in range(20):
+            s.step(nn)
+    s.close()
+    ref = _run_with_env(agx_rans, golden_case("wallLaw"), 2, {"AGX_SWEEP_PIPE": "0"})
+    got = _run_with_env(agx_rans, golden_case("wallLaw"), 2, {})
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["wallLaw", "rae2822", "turbFlatPlate"])
+def test_rans_viscous_forms_agree(agx_rans, name):
+    """The rans viscous residual face-once (k_rans_faces<D> + k_rans_cells, production)
+    against the one-thread-per-cell gather form (AGX_VISC=gather), which evaluates every
+    face twice: the same device functions, so the states agree to round-off (a product that
+    passes through memory is rounded where the gather form may contract it into an fma) --
+    on the reference's cases: wall functions + BLU-SGS on two blocks, SST + LU-SGS, Wilcox."""
+    ref = _run_with_env(agx_rans, golden_case(name), 3, {"AGX_VISC": "gather"})
+    got = _run_with_env(agx_rans, golden_case(name), 3, {})
+    assert rel_err(got, ref) < 1e-12
+
+
+@pytest.mark.gpu
 def test_rans4_at_bench_size_against_the_simple_forms(agx_rans):
     """BASELINE configs[4] at the size `bench.py --workload rans4` times (4 blocks of
     128 x 128 x 64, k-omega SST 2003, BLU-SGS, the flat-plate start): the production sweep
-    form (all blocks per launch, cell-major records, three lanes per cell) against the simple
-    ones -- one lane per cell, and plane-major loads -- bit for bit over four iterations;
+    form (one pipelined launch per half sweep, 256 k-planes side by side) against the
+    launch-per-hyperplane ones -- three lanes per cell, one lane per cell, and plane-major
+    loads -- bit for bit over four iterations;
     every norm finite, the run repeatable."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -830,10 +871,12 @@ def test_rans4_at_bench_size_against_the_simple_forms(agx_rans):
     assert np.all(np.isfinite(h0)) and np.all(h0[:, -1] > 0.0)
     for st in s0:
         assert np.all(np.isfinite(st)) and np.all(st[..., 0] > 0.0) and np.all(st[..., 4] > 0.0)
-    h1, s1 = run({"AGX_SWEEP_THREE": "0"}, 4)
+    h1, s1 = run({"AGX_SWEEP_PIPE": "0"}, 4)
     assert np.array_equal(h0, h1)
     for a, b in zip(s0, s1):
         assert np.array_equal(a, b)
+    h1, s1 = run({"AGX_SWEEP_PIPE": "0", "AGX_SWEEP_THREE": "0"}, 2)
+    assert np.array_equal(h0[:2], h1)
     h2, s2 = run({"AGX_SWEEP_RECORDS": "0", "AGX_SWEEP_ALL": "0"}, 2)
     assert np.array_equal(h0[:2], h2)
     h3, _ = run({}, 4)
@@ -864,7 +907,14 @@ def test_user_stream_and_stream_change(agx, agx_rans, lib):
     and a change of stream between two iterations, give the states of the default stream
     bit for bit (5-equation LU-SGS on the diagonal-ordered path; wallLaw on the
     hyperplane graphs)."""
-    hip = ctypes.CDLL("libamdhip64.so")
+    # the HIP runtime the libraries are linked to -- the copy already mapped into this
+    # process (a second copy loaded by name would be a second runtime with its own devices)
+    # (torch, when imported, maps a private copy of its own beside it)
+    with open("/proc/self/maps") as f:
+        paths = sorted({ln.split()[-1] for ln in f if "libamdhip64.so" in ln},
+                       key=lambda p: "/torch/" in p)
+    assert paths, "no HIP runtime mapped"
+    hip = ctypes.CDLL(paths[0])
 
     def new_stream():
         st = ctypes.c_void_p()
