@@ -821,13 +821,37 @@ static int lusgs_sweep_pipe(agx_ctx* c, bool forward, int full) {
   pa.njobs = c->pipe_njobs;
   pa.spin_limit = c->spin_limit;
   pa.err = c->err_dev;
+  pa.trace = nullptr;
+#ifdef AGX_PIPE_TRACE
+  static long long* trace_dev = nullptr;
+  const size_t trace_n = 5 * (size_t)(c->pipe_maxsteps + 1);
+  if (getenv("AGX_PIPE_TRACE")) {
+    if (!trace_dev) hipMalloc((void**)&trace_dev, sizeof(long long) * 5 * 65536);
+    hipMemsetAsync(trace_dev, 0, sizeof(long long) * trace_n, c->stream);
+    pa.trace = trace_dev;
+  }
+#endif
   ++c->pipe_launches;
-  const dim3 tb(64, c->pipe_waves), grid((unsigned)c->pipe_njobs);
+  const dim3 grid((unsigned)c->pipe_njobs);
+  const dim3 tb(64, c->pipe_waves);
   if (forward)
     hipLaunchKernelGGL((k_lusgs_pipe<true>), grid, tb, 0, c->stream, c->blocks_tab, c->gas, c->sp, full, pa);
   else
     hipLaunchKernelGGL((k_lusgs_pipe<false>), grid, tb, 0, c->stream, c->blocks_tab, c->gas, c->sp, full, pa);
   HIPCHK(hipGetLastError());
+#ifdef AGX_PIPE_TRACE
+  if (pa.trace) {   // diagnostic build only: dump the step timestamps of this launch
+    std::vector<long long> h(trace_n);
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(h.data(), pa.trace, sizeof(long long) * trace_n, hipMemcpyDeviceToHost);
+    if (FILE* f = fopen(getenv("AGX_PIPE_TRACE"), "a")) {
+      fprintf(f, "# %s jobs %d\n", forward ? "fwd" : "bwd", c->pipe_njobs);
+      for (size_t t = 0; t + 5 <= trace_n; t += 5)
+        fprintf(f, "%lld %lld %lld %lld %lld\n", h[t], h[t + 1], h[t + 2], h[t + 3], h[t + 4]);
+      fclose(f);
+    }
+  }
+#endif
   return 0;
 }
 static int lusgs_sweep_all_one_launch(agx_ctx* c, bool forward, int full) {

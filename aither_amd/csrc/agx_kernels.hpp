@@ -2929,7 +2929,19 @@ k_lusgs_plane_all(const BlockDev* tab, GasDev g, SolverDev sp, int t, int full) 
 // The planes of a block therefore run as a pipeline one step apart; a rank's blocks side by
 // side (4 x 64 planes = 256 workgroups for BASELINE configs[4]).  Every cell gets the x of
 // exactly the neighbours the plane-per-launch forms give it: bit-identical results
-// (test_plane_sweep_forms_agree_bitwise), 636 launches of ~13 us less per sweep pair.
+// (test_plane_sweep_forms_agree_bitwise); one launch instead of 318 per half sweep.
+//
+// What a step costs (trace: -DAGX_PIPE_TRACE, tools/pipe_trace_summary.py; rans4, BLU-SGS):
+// the hand-off 0.5 us, the cells 4 - 5 us while one or two waves have any and 12 us with all
+// seven -- ~ 1000 dependent fp64 instructions per lane (the flux and thin-shear-layer
+// Jacobians of the neighbour, 34 divisions) behind two or three memory round trips, on one
+// or two waves per SIMD: the half sweep takes what 318 launches took, 3.9 against 4.1 ms.
+// Measured and dropped in round 3: the six off-diagonal matrices of a cell formed once per
+// iteration by a parallel kernel and multiplied here (7 GB written and read again per
+// iteration: 0.65 ms per block to form them and a sweep bound by the 256-byte records, 4.6
+// ms); the neighbours' records requested a step ahead into registers, four lanes per cell
+// (the step is bound by the chain of dependent instructions, not by the loads: 5.1 ms);
+// touching the next step's lines (+ 0.3 ms).
 //   * x is written with agent-scope (write-through) stores and read with agent-scope loads;
 //     what else a cell reads does not change during the launch.
 //   * hand-off between planes: a workgroup waits for its stores' acknowledgement, passes a
@@ -2949,7 +2961,14 @@ struct PipeArgs {
   unsigned long long tbase; // first ticket of this launch
   int njobs, spin_limit;
   int* err;
+  long long* trace;         // -DAGX_PIPE_TRACE builds: 5 timestamps per step of job njobs / 2
 };
+#ifdef AGX_PIPE_TRACE
+#define PIPE_STAMP(n) do { if (lane == 0 && wv == 0 && pa.trace && job == pa.njobs / 2) \
+    pa.trace[5 * t + (n)] = wall_clock64(); } while (0)
+#else
+#define PIPE_STAMP(n) do {} while (0)
+#endif
 template <bool FORWARD>
 __global__ void __launch_bounds__(512)
 k_lusgs_pipe(const BlockDev* tab, GasDev g, SolverDev sp, int full, PipeArgs pa) {
@@ -2960,11 +2979,13 @@ k_lusgs_pipe(const BlockDev* tab, GasDev g, SolverDev sp, int full, PipeArgs pa)
     s_bad = 0;
   }
   __syncthreads();
-  const int job = s_job;
+  // (the job is the same for the whole workgroup: said so, the block's descriptor is read
+  // with scalar loads)
+  const int job = __builtin_amdgcn_readfirstlane(s_job);
   if (job < 0 || job >= pa.njobs) return;
   const PipeJob jb = pa.jobs[job];
-  const BlockDev& b = tab[jb.block];
-  const int k = jb.k, kp = FORWARD ? k - 1 : k + 1;
+  const BlockDev& b = tab[__builtin_amdgcn_readfirstlane(jb.block)];
+  const int k = __builtin_amdgcn_readfirstlane(jb.k), kp = FORWARD ? k - 1 : k + 1;
   const bool has_pred = kp >= 0 && kp < b.nk;
   const long long* ppred = pa.progress + (long)(pa.slot0[jb.block] + (has_pred ? kp : k)) * 16;
   long long* pown = pa.progress + (long)(pa.slot0[jb.block] + k) * 16;
@@ -2973,6 +2994,7 @@ k_lusgs_pipe(const BlockDev* tab, GasDev g, SolverDev sp, int full, PipeArgs pa)
   for (int t = 0; t < nsteps; ++t) {
     const int s = FORWARD ? t : nsteps - 1 - t;
     bool ok = true;
+    PIPE_STAMP(0);
     if (has_pred) {
       int spins = 0;
       while (__hip_atomic_load(ppred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pa.base + t + 1) {
@@ -2985,6 +3007,7 @@ k_lusgs_pipe(const BlockDev* tab, GasDev g, SolverDev sp, int full, PipeArgs pa)
         }
       }
     }
+    PIPE_STAMP(1);
     if (ok) {
       const int ilo = max(0, s - (b.nj - 1)), ncell = min(b.ni - 1, s) - ilo + 1;
       for (int c0 = wv * PL3_CELLS; c0 < ncell; c0 += nw * PL3_CELLS) {
@@ -2995,8 +3018,11 @@ k_lusgs_pipe(const BlockDev* tab, GasDev g, SolverDev sp, int full, PipeArgs pa)
       s_bad = 1;
       __hip_atomic_store(pa.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    PIPE_STAMP(2);
     __builtin_amdgcn_s_waitcnt(0x0F70);     // this wave's stores of x have been acknowledged
+    PIPE_STAMP(3);
     __syncthreads();
+    PIPE_STAMP(4);
     if (s_bad) return;
     if (lane == 0 && wv == 0)
       __hip_atomic_store(pown, pa.base + t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
