@@ -528,7 +528,7 @@ __device__ inline void inv_flux_jacobian(const GasDev& g, const double* s, const
   const double phi = 0.5 * gm1 * dot3(s + 1, s + 1);
   double u[AGX_NF];
   prim_to_cons(g, s, u);
-  const double a1 = g.gamma * (u[4] / s[0]) - phi;    // primitive::Energy
+  const double a1 = g.gamma * (u[4] * fast_rcp(s[0])) - phi;    // primitive::Energy
   const double a3 = g.gamma - 2.0;
 #pragma unroll
   for (int q = 0; q < AGX_NJ; ++q) J[q] = 0.0;
@@ -594,17 +594,19 @@ __device__ inline void tsl_jacobian(const GasDev& g, const double* s, double lam
   // and its last row: the product MatrixMultiply (matrix.cpp:193-207) forms with 125
   // multiply-adds is written out on the 35 that are not products with a structural zero, in
   // the same order of summation (c ascending), so the result is the same number.
-  const double sc = area[3] * mu / dist;
+  // (three reciprocals -- 1 / mu, 1 / rho, 1 / dist -- for the function's eight quotients)
+  const double imu = fast_rcp(mu), ir = fast_rcp(rho), imr = imu * ir;
+  const double sc = area[3] * mu * fast_rcp(dist);
   double Tv[3][3], T4[AGX_NF];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) Tv[r][c] = (third * n[c] * n[r] + (r == c ? 1.0 : 0.0)) * sc;
-    T4[1 + c] = (fac * 0.5 * dist / mu * tau[c] + third * n[c] * vn + s[1 + c]) * sc;
+    T4[1 + c] = (fac * 0.5 * dist * imu * tau[c] + third * n[c] * vn + s[1 + c]) * sc;
   }
-  T4[0] = (-k * t / (mu * rho) + 0.0) * sc;
-  T4[4] = (k / (mu * rho)) * sc;
-  const double gm1 = g.gamma - 1.0, ir = 1.0 / rho;
+  T4[0] = (-k * t * imr + 0.0) * sc;
+  T4[4] = (k * imr) * sc;
+  const double gm1 = g.gamma - 1.0;
   double Pq0[3], P4q[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) { Pq0[q] = -ir * s[1 + q]; P4q[q] = -gm1 * s[1 + q]; }
@@ -714,9 +716,9 @@ __device__ __forceinline__ double turb_inv_jac(const double* s, const double* ar
 __device__ __forceinline__ void turb_visc_jac(const GasDev& g, const double* s, const double* area,
                                               double mu, double dist, double mut, double f1,
                                               double& jk, double& jw) {
-  const double len = area[3] / dist;
-  jk = g.scaling * len / s[0] * (mu + turb_sigma_k(g, f1) * turb_diff_visc(g, s, mut));
-  jw = g.scaling * len / s[0] * (mu + turb_sigma_w(g, f1) * turb_diff_visc(g, s, mut));
+  const double len = g.scaling * (area[3] * fast_rcp(dist)) * fast_rcp(s[0]);
+  jk = len * (mu + turb_sigma_k(g, f1) * turb_diff_visc(g, s, mut));
+  jw = len * (mu + turb_sigma_w(g, f1) * turb_diff_visc(g, s, mut));
 }
 __device__ inline void block_off_diagonal(const GasDev& g, bool viscous, const double* s,
                                           const double* du, const double* area, double mu,

@@ -242,12 +242,14 @@ LUSGS_PASSES = [
     ("M  matrix residual (k_matrix_resid_d2)", 280, (6,)),
     ("U  update + norms (k_update_d2, k_norm_final)", 160, (1,)),
 ]
-# rans on the one-thread-per-cell kernels: no per-pass byte model is claimed (the
-# kernels gather their stencils; bytes_per_cell = the 7-equation analogue of SURVEY 8d)
+# rans: the viscous residual face-once (k_rans_faces<D> + k_rans_cells), the half sweeps one
+# pipelined launch each (k_lusgs_pipe), the rest one thread per cell; no per-pass byte model
+# is claimed (bytes_per_cell = the 7-equation analogue of SURVEY 8d)
 RANS_PASSES = [
     ("R  residual + sources + dt + block diagonal (k_inv_residual, k_block_diag_inv, "
-     "k_visc_residual_rans)", 8 * (7 + 19 + 7 + 3 + 29), (0, 4, 5)),
-    ("F+B  BLU-SGS hyperplane sweeps (k_lusgs_plane)", 2 * 8 * (7 * 7 + 19 + 29 + 7), (3,)),
+     "k_rans_faces<0..2>, k_rans_cells)", 8 * (7 + 19 + 7 + 3 + 29), (0, 4, 5)),
+    ("F+B  BLU-SGS half sweeps, a workgroup per k-plane (k_lusgs_pipe x 2)",
+     2 * 8 * (7 * 7 + 19 + 29 + 7), (3,)),
     ("M  matrix residual", 8 * (7 * 7 + 19 + 29), (6,)),
     ("U  update + norms", 8 * (3 * 7), (1,)),
 ]
@@ -270,7 +272,8 @@ WORKLOAD_TEXT = {
     "rans4": ("residual+BLU-SGS, rans SST 2003",
               "4 blocks of {h}x{h}x{q} cells in a row shared by the GPUs, k-omega SST 2003 "
               "(7 equations), MUSCL thirdOrder + vanAlbada + Roe, viscous wall, implicit "
-              "Euler, BLU-SGS 1 sweep (one-thread-per-cell kernels, libaither_gfx950_rans.so)",
+              "Euler, BLU-SGS 1 sweep (libaither_gfx950_rans.so: face-once viscous kernels, "
+              "pipelined record sweeps)",
               "one nonlinear iteration (mgSolution::Iterate)"),
     "dplur8": ("residual + DPLUR",
                "2x2x2 blocks of {h}^3 cells shared by the GPUs, Euler MUSCL + AUSMPW+, "
