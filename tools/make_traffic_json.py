@@ -17,7 +17,9 @@ METHOD = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
           "streamed write 1048576 KB), WRITE_SIZE KB x1024")
 PASS_OF = [("k_residual_tile", "R"), ("k_inv_residual", "R"), ("k_block_diag", "R"),
            ("k_visc", "R"), ("k_lusgs_prepare", "R"), ("k_implicit_begin", "R"),
+           ("k_rans_faces", "R"), ("k_rans_cells", "R"),
            ("k_sweep_records", "F+B"), ("k_lusgs_kp", "F+B"), ("k_lusgs_plane", "F+B"),
+           ("k_lusgs_pipe", "F+B"),
            ("k_dplur", "4"), ("k_matrix_resid", "M"), ("k_update", "U"), ("k_norm_final", "U")]
 
 

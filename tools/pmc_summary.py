@@ -11,7 +11,8 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         cnt[k][c] += 1
 out = {}
 for k in acc:
-    if not any(t in k for t in ("residual", "update", "norm", "lusgs", "visc", "dplur", "implicit", "matrix", "bc_", "halo")):
+    if not any(t in k for t in ("residual", "update", "norm", "lusgs", "visc", "dplur", "implicit", "matrix", "bc_", "halo",
+                                "rans", "sweep_records", "block_diag", "store_time")):
         continue
     out[k] = {c: acc[k][c] / cnt[k][c] for c in sorted(acc[k])}
     out[k]["launches_seen"] = max(cnt[k].values())
