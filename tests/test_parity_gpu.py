@@ -985,6 +985,21 @@ def test_rans_synthetic_parity(agx_rans, oracle, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,solver", [((6, 5, 700), "blusgs"), ((6, 5, 700), "lusgs"),
+                                      ((180, 172, 3), "blusgs")])
+def test_pipelined_sweep_shapes(agx_rans, oracle, n, solver):
+    """k_lusgs_pipe outside the shape it was tuned on: 700 k-planes (more workgroups than the
+    GPU holds at once: planes wait for tickets, a plane's predecessor always has a lower one)
+    and diagonals of 172 cells (more than seven waves of 21: the cells of a step in two
+    passes) -- parity with the oracle, two sweeps (both triangles), block and scalar."""
+    case = synthetic.single_block_case(n=n, stretch=1.05, bcs=RANS_WALL, equation_set="rans",
+                                       turbulence_model="sst2003",
+                                       time_integration="implicitEuler", cfl=10.0,
+                                       matrix_solver=solver, matrix_sweeps=2)
+    _close(*run_pair(agx_rans, oracle, case, 2))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("vel", [(50.0, 20.0, 10.0), (420.0, 20.0, 10.0)])
 def test_rans_inlet_and_supersonic_boundaries_parity(agx_rans, oracle, vel):
     """rans ghost states of inlet (subsonic: characteristics both ways; supersonic: the free
