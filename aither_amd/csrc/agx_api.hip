@@ -43,6 +43,7 @@ struct Block {
   double* d2 = nullptr;       // D2 arrays of the LU-SGS path (agx_lusgs.hpp)
   double* blockmat = nullptr; // block-matrix solvers: a_ | aInv_ | velocityGrad_ planes
   double* sweep_rec = nullptr; // plane-by-plane sweeps: geo | dyn | rhs records (k_sweep_records)
+  bool sweep_geo_built = false; // the (static) geometry records exist
   int* d2_tab = nullptr;      // device: dstart[Pi + Pj] | ij_of_pos[Pi * Pj]
   std::vector<int> dstart;    // host copy (halo index maps)
   // hyperplane-per-launch sweeps captured as graphs: [forward][both triangles][un_is_u]
@@ -2139,9 +2140,11 @@ int agx_phase_implicit_begin(agx_ctx* c) {
                          c->stream, planes(b.x), b.nplane);
     hipLaunchKernelGGL(k_implicit_begin, cell_grid(b, CELL_BLOCK), CELL_BLOCK, 0,
                        c->stream, b, c->gas, c->sp, c->err_dev);
-    if (b.sw_geo)
+    if (b.sw_geo) {
       hipLaunchKernelGGL(k_sweep_records, dim3((unsigned)((b.nplane + 255) / 256)), dim3(256), 0,
-                         c->stream, b, c->sp);
+                         c->stream, b, c->sp, blk.sweep_geo_built ? 0 : 1);
+      blk.sweep_geo_built = true;
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;

@@ -2521,7 +2521,8 @@ __device__ __forceinline__ void add_off_diag(const BlockDev& b, const GasDev& g,
 //             (Planes5::rec) and by the sweeps themselves beside the plane-major x
 //   rhs  [8]: the right-hand side b of the cell (k_implicit_begin)
 // so that a neighbour costs three lines instead of forty-two.
-__global__ void __launch_bounds__(256) k_sweep_records(BlockDev b, SolverDev sp) {
+// (with_geo: the geometry records are static, written by the first launch of a block only)
+__global__ void __launch_bounds__(256) k_sweep_records(BlockDev b, SolverDev sp, int with_geo) {
   // 256 consecutive cells per workgroup: plane-major reads (coalesced), the records of
   // the 256 cells written as one contiguous run through LDS (row stride 33: the
   // write-out walks consecutive words)
@@ -2529,25 +2530,27 @@ __global__ void __launch_bounds__(256) k_sweep_records(BlockDev b, SolverDev sp)
   const int tid = threadIdx.x;
   const long t0 = (long)blockIdx.x * 256, t = t0 + tid;
   const long ncell = min(256L, b.nplane - t0);
-  if (t < b.nplane) {
+  if (with_geo) {       // (kernel argument: uniform)
+    if (t < b.nplane) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) sh[tid][r] = b.cen[r][t];
+      for (int r = 0; r < 3; ++r) sh[tid][r] = b.cen[r][t];
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+      for (int d = 0; d < 3; ++d)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) sh[tid][3 + 4 * d + c] = b.fa[d][c][t];
-    sh[tid][15] = 0.0;
-  }
-  __syncthreads();
-  {
-    double* out = b.sw_geo + t0 * SW_GEO;
-#pragma unroll
-    for (int m = 0; m < SW_GEO; ++m) {
-      const int idx = m * 256 + tid;
-      if (idx < ncell * SW_GEO) out[idx] = sh[idx / SW_GEO][idx % SW_GEO];
+        for (int c = 0; c < 4; ++c) sh[tid][3 + 4 * d + c] = b.fa[d][c][t];
+      sh[tid][15] = 0.0;
     }
+    __syncthreads();
+    {
+      double* out = b.sw_geo + t0 * SW_GEO;
+#pragma unroll
+      for (int m = 0; m < SW_GEO; ++m) {
+        const int idx = m * 256 + tid;
+        if (idx < ncell * SW_GEO) out[idx] = sh[idx / SW_GEO][idx % SW_GEO];
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (t < b.nplane) {
 #pragma unroll
     for (int e = 0; e < SW_DYN; ++e) sh[tid][e] = 0.0;
