@@ -137,6 +137,12 @@ SYMBOLS = {
     "restart_pack": (_i, [_vp, _i, _i, c_dp]),
     "plot3d_metrics": (_i, [_vp, _i, _i, _i] + [c_dp] * 9),
     "nearest_wall_distance": (_i, [_vp, C.c_int64, c_dp, C.c_int64, c_dp, c_dp]),
+    "mg_restrict": (_i, [_vp, _vp, _i, _i, C.POINTER(C.c_int32), c_dp]),
+    "mg_matrix_residual": (_i, [_vp, c_dp]),
+    "mg_invert_diagonal": (_i, [_vp]),
+    "mg_save_update": (_i, [_vp]),
+    "mg_reset_diagonal": (_i, [_vp]),
+    "mg_prolong": (_i, [_vp, _vp, _i, C.POINTER(C.c_int32), c_dp]),
     "store_time_n": (_i, [_vp, _i]),
     "iterate": (_i, [_vp, _i, C.c_double, c_dp, C.POINTER(Linf), c_dp]),
     "phase_bc_faces": (_i, [_vp]),

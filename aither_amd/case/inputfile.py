@@ -109,6 +109,7 @@ class InputDeck:
     turbulence_model: str = "none"
     thermodynamic_model: str = "caloricallyPerfect"
     multigrid_levels: int = 1
+    multigrid_cycle: str = "V"
     ics: List[State] = field(default_factory=list)
     bc_states: List[State] = field(default_factory=list)
     bcs: List[List[Surface]] = field(default_factory=list)
@@ -340,6 +341,8 @@ def parse_input(path):
             deck.thermodynamic_model = val
         elif key == "multigridLevels":
             deck.multigrid_levels = int(val)
+        elif key == "multigridCycle":
+            deck.multigrid_cycle = val
         elif key in ("outputVariables", "wallOutputVariables"):
             read_list(val)
         elif key == "initialConditions":

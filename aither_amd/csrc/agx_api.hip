@@ -44,6 +44,14 @@ struct Block {
   double* blockmat = nullptr; // block-matrix solvers: a_ | aInv_ | velocityGrad_ planes
   double* sweep_rec = nullptr; // plane-by-plane sweeps: geo | dyn | rhs records (k_sweep_records)
   bool sweep_geo_built = false; // the (static) geometry records exist
+  // multigrid: forcing | matrix residual | saved update planes (each allocated on first
+  // use); the transfer maps of this block as the FINE side (device copies, keyed by the
+  // host pointers they were uploaded from); node values of this block as the coarse side
+  double *mg_forcing = nullptr, *mg_mres = nullptr, *mg_xsave = nullptr, *mg_nodes = nullptr;
+  int* mg_tc = nullptr;
+  int* mg_start = nullptr;
+  double *mg_vf = nullptr, *mg_cf = nullptr;
+  const void *mg_tc_key = nullptr, *mg_vf_key = nullptr, *mg_cf_key = nullptr;
   int* d2_tab = nullptr;      // device: dstart[Pi + Pj] | ij_of_pos[Pi * Pj]
   std::vector<int> dstart;    // host copy (halo index maps)
   // hyperplane-per-launch sweeps captured as graphs: [forward][both triangles][un_is_u]
@@ -153,6 +161,7 @@ struct agx_ctx {
   size_t blocks_tab_n = 0;
   hipGraphExec_t sweep_graph_all[2][2][2] = {};
   // the pipelined half sweep (k_lusgs_pipe): a workgroup per k-plane of every block
+  bool mg_coarse = false;                // a coarse multigrid level (agx_mg_restrict made it one)
   bool sweep_pipe = true;                // AGX_SWEEP_PIPE=0: one launch per hyperplane
   PipeJob* pipe_jobs[2] = {nullptr, nullptr};   // device: pipeline order back / forward
   int* pipe_slot0 = nullptr;             // device
@@ -1166,6 +1175,9 @@ void agx_ctx_destroy(agx_ctx* c) {
     if (b.d2) hipFree(b.d2);
     if (b.blockmat) hipFree(b.blockmat);
     if (b.sweep_rec) hipFree(b.sweep_rec);
+    for (void* p : {(void*)b.mg_forcing, (void*)b.mg_mres, (void*)b.mg_xsave, (void*)b.mg_nodes,
+                    (void*)b.mg_tc, (void*)b.mg_start, (void*)b.mg_vf, (void*)b.mg_cf})
+      if (p) hipFree(p);
     if (b.d2_tab) hipFree(b.d2_tab);
     if (b.kp_mem) hipFree(b.kp_mem);
     for (auto& g1 : b.sweep_graph) for (auto& g2 : g1) for (auto& g3 : g2)
@@ -1286,6 +1298,7 @@ int agx_config_set(agx_ctx* c, const agx_config* cfg) {
   c->gas.sstdes = cfg->turbulence_model == AGX_TURB_SST_DES ? 1 : 0;
   c->gas.turb_prandtl = c->gas.wilcox ? 8.0 / 9.0 : 0.9;
   SolverDev& sp = c->sp;
+  sp.diag_add = 0;
   sp.kappa = cfg->kappa;
   sp.theta = cfg->theta;
   sp.zeta = cfg->zeta;
@@ -1359,6 +1372,7 @@ int agx_block_create(agx_ctx* c, const agx_block_geom* g, int* block_id) {
     d.aminv_t = d.am_t + (size_t)d.nplane * 2;
   }
   d.sw_geo = d.sw_dyn = d.sw_rhs = nullptr;
+  d.mg_forcing = d.mg_mres = d.mg_xsave = nullptr;
   if (c->sp.implicit && is_lusgs_solver(c) && !use_d2(c) && c->sweep_records) {
     const size_t n = (size_t)d.nplane * (SW_GEO + SW_DYN + SW_RHS);
     HIPCHK(hipMalloc((void**)&b.sweep_rec, sizeof(double) * n));
@@ -1967,6 +1981,174 @@ int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
   return 0;
 }
 
+// ---- geometric multigrid (include/aither_gfx950.h) -------------------------------------------
+static int implicit_begin(agx_ctx* c, int write_x);
+int agx_phase_matrix_residual(agx_ctx* c, double* mr);
+namespace {
+int mg_check(agx_ctx* f, agx_ctx* cz, int blk) {
+  if (!f || !cz) return fail("mg: null context");
+  if (blk < 0 || blk >= (int)f->blocks.size() || blk >= (int)cz->blocks.size())
+    return fail("mg: bad block %d", blk);
+  if (f->device != cz->device) return fail("mg: the two levels live on different devices");
+  for (agx_ctx* c : {f, cz})
+    if (!(c->sp.implicit && c->cfg.matrix_solver == AGX_SOLVER_DPLUR) || c->blocks[blk].d.d2.base)
+      return fail("multigrid: built for scalar DPLUR");
+  return 0;
+}
+int mg_planes(agx_ctx* c, Block& b, double** p) {     // AGX_NEQ zeroed planes, once
+  if (*p) return 0;
+  HIPCHK(hipMalloc((void**)p, sizeof(double) * AGX_NEQ * b.d.nplane));
+  HIPCHK(hipMemsetAsync(*p, 0, sizeof(double) * AGX_NEQ * b.d.nplane, c->stream));
+  return 0;
+}
+// the device copies of a fine block's transfer maps (uploaded when the host pointer changes)
+int mg_maps(agx_ctx* f, Block& b, const int32_t* tc, const double* vf, const double* cf,
+            int cni, int cnj, int cnk, MgMap* m) {
+  const BlockDev& d = b.d;
+  const size_t ncell = (size_t)d.ni * d.nj * d.nk;
+  if (tc && b.mg_tc_key != tc) {
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (!b.mg_tc) HIPCHK(hipMalloc((void**)&b.mg_tc, sizeof(int) * 3 * ncell));
+    HIPCHK(hipMemcpy(b.mg_tc, tc, sizeof(int) * 3 * ncell, hipMemcpyHostToDevice));
+    // first fine index of every coarse cell, per direction (the map is a product of three
+    // monotone 1-D maps: procBlock.cpp:6556-6581)
+    std::vector<int> st((size_t)cni + cnj + cnk + 3, 0);
+    int* s0 = st.data();
+    int* s1 = s0 + cni + 1;
+    int* s2 = s1 + cnj + 1;
+    const int n[3] = {d.ni, d.nj, d.nk}, cn[3] = {cni, cnj, cnk};
+    int* ss[3] = {s0, s1, s2};
+    for (int dir = 0; dir < 3; ++dir) {
+      int cc = 0;
+      ss[dir][0] = 0;
+      for (int q = 0; q < n[dir]; ++q) {
+        const size_t cell = dir == 0 ? (size_t)q : dir == 1 ? (size_t)q * d.ni : (size_t)q * d.ni * d.nj;
+        const int to = tc[3 * cell + dir];
+        if (to < 0 || to >= cn[dir] || to < cc) return fail("mg: to_coarse is not a monotone map onto the coarse block");
+        while (cc < to) ss[dir][++cc] = q;
+      }
+      while (cc < cn[dir]) ss[dir][++cc] = n[dir];
+    }
+    if (b.mg_start) HIPCHK(hipFree(b.mg_start));
+    HIPCHK(hipMalloc((void**)&b.mg_start, sizeof(int) * st.size()));
+    HIPCHK(hipMemcpy(b.mg_start, st.data(), sizeof(int) * st.size(), hipMemcpyHostToDevice));
+    b.mg_tc_key = tc;
+  }
+  if (vf && b.mg_vf_key != vf) {
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (!b.mg_vf) HIPCHK(hipMalloc((void**)&b.mg_vf, sizeof(double) * ncell));
+    HIPCHK(hipMemcpy(b.mg_vf, vf, sizeof(double) * ncell, hipMemcpyHostToDevice));
+    b.mg_vf_key = vf;
+  }
+  if (cf && b.mg_cf_key != cf) {
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (!b.mg_cf) HIPCHK(hipMalloc((void**)&b.mg_cf, sizeof(double) * 7 * ncell));
+    HIPCHK(hipMemcpy(b.mg_cf, cf, sizeof(double) * 7 * ncell, hipMemcpyHostToDevice));
+    b.mg_cf_key = cf;
+  }
+  if (!b.mg_tc) return fail("mg: no fine-to-coarse map for this block yet");
+  m->tc = b.mg_tc;
+  m->start[0] = b.mg_start;
+  m->start[1] = b.mg_start + cni + 1;
+  m->start[2] = m->start[1] + cnj + 1;
+  m->vf = b.mg_vf;
+  m->cf = b.mg_cf;
+  return 0;
+}
+// the other level's stream has finished what it was given (the two contexts may run on
+// different streams)
+int mg_order(agx_ctx* producer, agx_ctx* consumer) {
+  if (producer->stream != consumer->stream) HIPCHK(hipStreamSynchronize(producer->stream));
+  return 0;
+}
+}  // namespace
+
+int agx_mg_restrict(agx_ctx* f, agx_ctx* cz, int blk, int what, const int32_t* tc,
+                    const double* vf) {
+  if (mg_check(f, cz, blk)) return 1;
+  Block &bf = f->blocks[blk], &bc = cz->blocks[blk];
+  if (what < AGX_MG_STATE || what > AGX_MG_FORCING) return fail("mg_restrict: bad selector %d", what);
+  if (what != AGX_MG_FORCING && !vf) return fail("mg_restrict: volume weights missing");
+  if (flush_consn(f) || flush_consn(cz)) return 1;
+  MgMap m;
+  if (mg_maps(f, bf, tc, vf, nullptr, bc.d.ni, bc.d.nj, bc.d.nk, &m)) return 1;
+  if (mg_order(f, cz)) return 1;
+  if (what == AGX_MG_STATE) {
+    // (coarse.Zero(): ghost cells included, procBlock.hpp:641)
+    for (int e = 0; e < AGX_NEQ; ++e)
+      HIPCHK(hipMemsetAsync(bc.d.state[e], 0, sizeof(double) * bc.d.nplane, cz->stream));
+    cz->ghosts_prefilled = false;
+    cz->state_is_time_n = false;
+    cz->mg_coarse = true;
+  } else if (what == AGX_MG_UPDATE) {
+    for (int e = 0; e < AGX_NEQ; ++e)
+      HIPCHK(hipMemsetAsync(bc.d.x[e], 0, sizeof(double) * bc.d.nplane, cz->stream));
+  } else {
+    if (!bf.d.mg_mres) return fail("mg_restrict: the fine level has no matrix residual yet");
+    if (mg_planes(cz, bc, &bc.mg_forcing)) return 1;
+    bc.d.mg_forcing = bc.mg_forcing;
+  }
+  hipLaunchKernelGGL(k_mg_restrict, cell_grid(bc.d, CELL_BLOCK), CELL_BLOCK, 0, cz->stream, bf.d,
+                     bc.d, m, what);
+  if (what == AGX_MG_FORCING)
+    hipLaunchKernelGGL(k_mg_axmb, cell_grid(bc.d, CELL_BLOCK), CELL_BLOCK, 0, cz->stream, bc.d,
+                       cz->gas, cz->sp);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int agx_mg_matrix_residual(agx_ctx* c, double* mr) {
+  for (auto& blk : c->blocks) {
+    if (blk.d.d2.base) return fail("multigrid: built for scalar DPLUR");
+    if (mg_planes(c, blk, &blk.mg_mres)) return 1;
+    blk.d.mg_mres = blk.mg_mres;
+  }
+  return agx_phase_matrix_residual(c, mr);
+}
+
+int agx_mg_invert_diagonal(agx_ctx* c) { return implicit_begin(c, 0); }
+
+// gridLevel::ResetDiagonal (gridLevel.cpp:408-412) of a coarse level, whose residual adds to the
+// diagonal (SolverDev::diag_add); the finest level's kernels overwrite theirs
+int agx_mg_reset_diagonal(agx_ctx* c) {
+  for (auto& blk : c->blocks)
+    HIPCHK(hipMemsetAsync(blk.d.a, 0, sizeof(double) * blk.d.nplane, c->stream));
+  return 0;
+}
+
+int agx_mg_save_update(agx_ctx* c) {
+  for (auto& blk : c->blocks) {
+    if (mg_planes(c, blk, &blk.mg_xsave)) return 1;
+    blk.d.mg_xsave = blk.mg_xsave;
+    hipLaunchKernelGGL(k_mg_axpy, dim3((unsigned)((blk.d.nplane + 255) / 256)), dim3(256), 0,
+                       c->stream, blk.d, 1);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int agx_mg_prolong(agx_ctx* cz, agx_ctx* f, int blk, const int32_t* tc, const double* cf) {
+  if (mg_check(f, cz, blk)) return 1;
+  Block &bf = f->blocks[blk], &bc = cz->blocks[blk];
+  if (!bc.d.mg_xsave) return fail("mg_prolong: no saved update on the coarse level");
+  if (!cf) return fail("mg_prolong: interpolation coefficients missing");
+  MgMap m;
+  if (mg_maps(f, bf, tc, nullptr, cf, bc.d.ni, bc.d.nj, bc.d.nk, &m)) return 1;
+  const long nn = (long)(bc.d.ni + 1) * (bc.d.nj + 1) * (bc.d.nk + 1);
+  if (!bc.mg_nodes) HIPCHK(hipMalloc((void**)&bc.mg_nodes, sizeof(double) * AGX_NEQ * nn));
+  hipLaunchKernelGGL(k_mg_axpy, dim3((unsigned)((bc.d.nplane + 255) / 256)), dim3(256), 0,
+                     cz->stream, bc.d, 0);
+  const dim3 tb = CELL_BLOCK;
+  hipLaunchKernelGGL(k_mg_nodes, dim3((bc.d.ni + tb.x) / tb.x, (bc.d.nj + tb.y) / tb.y, bc.d.nk + 1),
+                     tb, 0, cz->stream, bc.d, bc.mg_nodes);
+  HIPCHK(hipGetLastError());
+  if (mg_order(cz, f)) return 1;
+  hipLaunchKernelGGL(k_mg_prolong, cell_grid(bf.d, tb), tb, 0, f->stream, bf.d, m,
+                     (const double*)bc.mg_nodes, bc.d.ni, bc.d.nj, bc.d.nk);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int agx_store_time_n(agx_ctx* c, int also_nm1) {
   if (flush_consn(c)) return 1;
   c->have_time_n = true;
@@ -1995,6 +2177,7 @@ int agx_phase_bc_edges(agx_ctx* c) { Timer t(c, G_BC); return bc_pass(c, false, 
 int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
   if (c->cfg.dt_nondim <= 0.0 && cfl <= 0.0)
     return fail("Neither dt or cfl was specified!");   // procBlock.cpp:813-816
+  c->sp.diag_add = c->mg_coarse ? 1 : 0;
   const bool fuse = can_fuse(c);
   const int store_consn = !c->use_gather && all_tile_ok(c) && c->consn_pending && mm == 0;
   if (store_consn) c->consn_pending = false;
@@ -2117,12 +2300,18 @@ int agx_phase_explicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
   return update_pass(c, mode, mm, l2, linf);
 }
 
-int agx_phase_implicit_begin(agx_ctx* c) {
+static int implicit_begin(agx_ctx* c, int write_x);
+int agx_phase_implicit_begin(agx_ctx* c) { return implicit_begin(c, 1); }
+// (write_x = 0: gridLevel::InvertDiagonal alone, for a coarse multigrid level)
+static int implicit_begin(agx_ctx* c, int write_x) {
   Timer t(c, G_PREPARE);
   c->sp.un_is_u = c->state_is_time_n ? 1 : 0;   // (read by every rhs_b of this iteration)
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
 #if AGX_FAST
+    if (b.d2.base && !write_x)
+      return fail("multigrid: built for scalar DPLUR (the diagonal-ordered LU-SGS path has no "
+                  "forcing term)");
     if (b.d2.base) {
       // diagonal terms, b and x0 straight into the D2 arrays of the sweeps
       const dim3 grid((b.d2.Pi + TT - 1) / TT, (b.d2.Pj + TT - 1) / TT, b.nk + 2 * b.ng);
@@ -2135,11 +2324,11 @@ int agx_phase_implicit_begin(agx_ctx* c) {
       continue;
     }
 #endif
-    if (!c->sp.requires_init)   // x_[bb].Zero() incl. ghosts, linearSolver.cpp:141
+    if (!c->sp.requires_init && write_x)   // x_[bb].Zero() incl. ghosts, linearSolver.cpp:141
       hipLaunchKernelGGL(k_zero5, dim3((b.nplane + 255) / 256), dim3(256), 0,
                          c->stream, planes(b.x), b.nplane);
     hipLaunchKernelGGL(k_implicit_begin, cell_grid(b, CELL_BLOCK), CELL_BLOCK, 0,
-                       c->stream, b, c->gas, c->sp, c->err_dev);
+                       c->stream, b, c->gas, c->sp, c->err_dev, write_x);
     if (b.sw_geo) {
       hipLaunchKernelGGL(k_sweep_records, dim3((unsigned)((b.nplane + 255) / 256)), dim3(256), 0,
                          c->stream, b, c->sp, blk.sweep_geo_built ? 0 : 1);

@@ -60,6 +60,12 @@ struct BlockDev {
   double* sw_geo;
   double* sw_dyn;
   double* sw_rhs;
+  // multigrid (null on a level without): mgForcing_, the matrix residual of the last
+  // agx_mg_matrix_residual, coarseDu -- AGX_NEQ planes each, entry e of cell q at
+  // [e * nplane + q]
+  double* mg_forcing;
+  double* mg_mres;
+  double* mg_xsave;
   D2Dev d2;                   // diagonal-ordered arrays of the LU-SGS path (agx_lusgs.hpp)
   const agx_bc_surface* surf; // boundaryConditions      boundaryConditions.hpp:231
   int nsurf, nsurf_i, nsurf_j, nsurf_k;
@@ -142,6 +148,10 @@ struct SlabDev {               // compact view used by the marching kernel
 struct SolverDev {   // scalar run-time parameters of agx_config
   double kappa, theta, zeta, relax, dual_time_cfl, dt_fixed, visc_cfl_coeff;
   int viscous, implicit, bdf2, requires_init, time_integration;
+  // a coarse multigrid level: the inviscid residual ADDS its spectral radii to the main
+  // diagonal, as the reference does everywhere (CalcInvFluxI/J/K; ResetDiagonal when an
+  // iteration ends) -- a level restricted to twice in a W cycle keeps its first visit's
+  int diag_add;
   int roe_jacobian;    // inviscidFluxJacobian: approximateRoe (RoeOffDiagonal)
   // the state has not changed since AssignSolToTimeN: U - U_n of the implicit
   // right-hand side (procBlock.cpp:1037, linearSolver.cpp:370) is exactly zero and
@@ -306,7 +316,7 @@ k_inv_residual(BlockDev b, GasDev g, SolverDev sp, double cfl) {
   }
   store5(b.resid, q, res);
   b.specrad[q] = sr;
-  if (sp.implicit) b.a[q] = sr;
+  if (sp.implicit) b.a[q] = sp.diag_add ? b.a[q] + sr : sr;
   if (AGX_NEQ > 5) {
     b.specrad_t[q] = srt;
     if (sp.implicit) b.a_t[q] = srt;
@@ -514,7 +524,7 @@ k_residual_march(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
 #pragma unroll
         for (int e = 0; e < AGX_NEQ; ++e) b.pl(PL_RESID + e)[q] = res[e];
         b.pl(PL_SPECRAD)[q] = sr;
-        if (sp.implicit) b.pl(PL_A)[q] = sr;
+        if (sp.implicit) b.pl(PL_A)[q] = sp.diag_add ? b.pl(PL_A)[q] + sr : sr;
         if (!sp.viscous) b.pl(PL_DT)[q] = dt;
         if (FUSE) {
           double u[AGX_NEQ], ns[AGX_NEQ];
@@ -950,7 +960,7 @@ k_residual_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, MarchArgs ma) {
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) b.stb(PL_RESID + e, qb, res[e]);
           b.stb(PL_SPECRAD, qb, sr);
-          if (sp.implicit) b.stb(PL_A, qb, sr);
+          if (sp.implicit) b.stb(PL_A, qb, sp.diag_add ? b.ldb(PL_A, qb) + sr : sr);
           if (!sp.viscous) b.stb(PL_DT, qb, dt);
           if (FUSE == 0 && ma.store_consn) {   // AssignSolToTimeN (procBlock.cpp:1037) rides along
             double u0[AGX_NEQ];
@@ -2653,7 +2663,7 @@ __device__ __forceinline__ void add_off_diag_rec(const BlockDev& b, const GasDev
 // linearSolver::AddDiagonalTerms :146-175, Invert :177-188,
 // InitializeMatrixUpdate :111-144
 __global__ void __launch_bounds__(256)
-k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err) {
+k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err, int write_x) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
@@ -2715,9 +2725,10 @@ k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err) {
 #pragma unroll
       for (int e = 5; e < AGX_NEQ; ++e) x0[e] = it[e - 5] * rb[e];
     }
-    store5(b.x, q, x0);
+    if (write_x) store5(b.x, q, x0);
     return;
   }
+  if (!write_x) return;       // (a coarse multigrid level: x is the restricted one)
   if (sp.requires_init) {
     rhs_b(b, g, sp, q, x0);
 #pragma unroll
@@ -3051,8 +3062,11 @@ k_dplur(BlockDev b, GasDev g, SolverDev sp) {
   add_off_diag(b, g, sp, b.xold, i, j, k, q, false, -1.0, acc);
   rhs_b(b, g, sp, q, rb);
   double out[AGX_NEQ];
+  // b + forcing + offDiagonal (linearSolver.cpp:503; the forcing term of a coarse multigrid
+  // level)
 #pragma unroll
-  for (int e = 0; e < AGX_NEQ; ++e) acc[e] = rb[e] + acc[e];
+  for (int e = 0; e < AGX_NEQ; ++e)
+    acc[e] = (b.mg_forcing ? rb[e] + b.mg_forcing[(long)e * b.nplane + q] : rb[e]) + acc[e];
   apply_ainv(b, sp, q, acc, out);
   store5(b.x, q, out);
 }
@@ -3086,11 +3100,145 @@ k_matrix_resid(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e) ax[e] = xc[e] * (e < 5 ? a : at);
     }
+    // matrix residual = f - (A x - b), linearSolver.cpp:92-109
 #pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) r[e] = -(ax[e] - acc[e] - rb[e]);
+    for (int e = 0; e < AGX_NEQ; ++e) {
+      const double axmb = ax[e] - acc[e] - rb[e];
+      r[e] = b.mg_forcing ? b.mg_forcing[(long)e * b.nplane + q] - axmb : -axmb;
+      if (b.mg_mres) b.mg_mres[(long)e * b.nplane + q] = r[e];
+    }
   }
   const long bid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   norm_block_reduce(r, 0, active, partials + bid);
+}
+
+// ---- geometric multigrid: transfers between a level and the next coarser one ---------------
+// (gridLevel.cpp:538-611; a level is a context of its own, include/aither_gfx950.h)
+struct MgMap {
+  const int* tc;        // fine cell -> coarse cell, [nk][nj][ni][3]
+  const int* start[3];  // per direction: first fine index of coarse cell c, [n_coarse + 1]
+  const double* vf;     // volume weights [nk][nj][ni]
+  const double* cf;     // trilinear coefficients [nk][nj][ni][7]
+};
+// BlockRestriction procBlock.hpp:636-690: a coarse cell adds up its fine cells in k, j, i
+// order (the order in which the reference's loop over the fine cells reaches them).
+// what 0: state, volume weighted; 1: x, volume weighted; 2: matrix residual -> forcing, summed
+__global__ void __launch_bounds__(256)
+k_mg_restrict(BlockDev f, BlockDev c, MgMap m, int what) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= c.ni || j >= c.nj) return;
+  double acc[AGX_NEQ];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) acc[e] = 0.0;
+  for (int fk = m.start[2][k]; fk < m.start[2][k + 1]; ++fk)
+    for (int fj = m.start[1][j]; fj < m.start[1][j + 1]; ++fj)
+      for (int fi = m.start[0][i]; fi < m.start[0][i + 1]; ++fi) {
+        const long q = f.idx(fi, fj, fk);
+        const long p = ((long)fk * f.nj + fj) * f.ni + fi;
+        const double w = what == 2 ? 1.0 : m.vf[p];
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) {
+          const double v = what == 0 ? f.state[e][q]
+                                     : (what == 1 ? f.x[e][q] : f.mg_mres[(long)e * f.nplane + q]);
+          acc[e] = what == 2 ? acc[e] + v : acc[e] + w * v;
+        }
+      }
+  const long qc = c.idx(i, j, k);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    if (what == 0) c.state[e][qc] = acc[e];
+    else if (what == 1) c.x[e][qc] = acc[e];
+    else c.mg_forcing[(long)e * c.nplane + qc] = acc[e];
+  }
+}
+// forcing += A x - b of the level (linearSolver::AXmB :58-90, gridLevel.cpp:579-589)
+__global__ void __launch_bounds__(256)
+k_mg_axmb(BlockDev b, GasDev g, SolverDev sp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  const long q = b.idx(i, j, k);
+  double acc[AGX_NEQ] = {0, 0, 0, 0, 0}, rb[AGX_NEQ], xc[AGX_NEQ];
+  add_off_diag(b, g, sp, b.x, i, j, k, q, true, 1.0, acc);
+  add_off_diag(b, g, sp, b.x, i, j, k, q, false, -1.0, acc);
+  rhs_b(b, g, sp, q, rb);
+  load5(b.x, q, xc);
+  const double a = b.a[q];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    double* fo = b.mg_forcing + (long)e * b.nplane + q;
+    *fo = (xc[e] * a - acc[e] - rb[e]) + *fo;
+  }
+}
+// x -= coarseDu, ghost cells included (linearSolver::SubtractFromUpdate :120-126);
+// save: coarseDu = x
+__global__ void k_mg_axpy(BlockDev b, int save) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.nplane) return;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    double* s = b.mg_xsave + (long)e * b.nplane + t;
+    if (save) *s = b.x[e][t];
+    else b.x[e][t] -= *s;
+  }
+}
+// ConvertCellToNode(coarse x, ignoreEdge, ignoreGhosts) utility.hpp:186-330: a node adds up
+// the physical cells around it in the order the reference's cell loop reaches them (k, j, i
+// ascending), times 1 at the block's corners, 1/2 on its edges, 1/8 elsewhere
+__global__ void __launch_bounds__(256)
+k_mg_nodes(BlockDev b, double* nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > b.ni || j > b.nj) return;
+  double acc[AGX_NEQ];
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) acc[e] = 0.0;
+  for (int dk = -1; dk <= 0; ++dk)
+    for (int dj = -1; dj <= 0; ++dj)
+      for (int di = -1; di <= 0; ++di) {
+        const int ci = i + di, cj = j + dj, ck = k + dk;
+        if (ci < 0 || ci >= b.ni || cj < 0 || cj >= b.nj || ck < 0 || ck >= b.nk) continue;
+        const long q = b.idx(ci, cj, ck);
+#pragma unroll
+        for (int e = 0; e < AGX_NEQ; ++e) acc[e] += b.x[e][q];
+      }
+  const bool xi = i == 0 || i == b.ni, xj = j == 0 || j == b.nj, xk = k == 0 || k == b.nk;
+  const double fac = (xi && xj && xk) ? 1.0 : ((xj && xk) || (xi && xk) || (xi && xj)) ? 0.5 : 0.125;
+  const long nn = (long)(b.ni + 1) * (b.nj + 1) * (b.nk + 1);
+  const long at = ((long)k * (b.nj + 1) + j) * (b.ni + 1) + i;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) nodes[(long)e * nn + at] = acc[e] * fac;
+}
+// BlockProlongation gridLevel.hpp:159-214 + AddToUpdate: fine x += TrilinearInterp of the
+// coarse nodes (utility.hpp:341-372)
+__global__ void __launch_bounds__(256)
+k_mg_prolong(BlockDev f, MgMap m, const double* nodes, int cni, int cnj, int cnk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= f.ni || j >= f.nj) return;
+  const long p = ((long)k * f.nj + j) * f.ni + i;
+  const int ci = m.tc[3 * p], cj = m.tc[3 * p + 1], ck = m.tc[3 * p + 2];
+  const double* w = m.cf + 7 * p;
+  const long nn = (long)(cni + 1) * (cnj + 1) * (cnk + 1);
+  auto nd = [&](int a, int b2, int c2, int e) {
+    return nodes[(long)e * nn + ((long)(ck + c2) * (cnj + 1) + (cj + b2)) * (cni + 1) + ci + a];
+  };
+  const long q = f.idx(i, j, k);
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) {
+    const double d04 = (1.0 - w[0]) * nd(0, 0, 0, e) + w[0] * nd(0, 0, 1, e);
+    const double d15 = (1.0 - w[1]) * nd(1, 0, 0, e) + w[1] * nd(1, 0, 1, e);
+    const double d26 = (1.0 - w[2]) * nd(0, 1, 0, e) + w[2] * nd(0, 1, 1, e);
+    const double d37 = (1.0 - w[3]) * nd(1, 1, 0, e) + w[3] * nd(1, 1, 1, e);
+    const double d0415 = (1.0 - w[4]) * d04 + w[4] * d15;
+    const double d2637 = (1.0 - w[5]) * d26 + w[5] * d37;
+    f.x[e][q] += (1.0 - w[6]) * d0415 + w[6] * d2637;
+  }
 }
 
 // Cell-centre gradients for output (velocityGrad_, temperatureGrad_, densityGrad_,

@@ -358,3 +358,146 @@ class PhasedSolver(Solver):
             api.check(api.phase_explicit_update(ctx, mm, l2p, C.byref(linf)),
                       "explicit_update")
         return l2, linf, mres.value
+
+
+class MultigridSolver:
+    """mgSolution with more than one grid level (mgSolution.cpp:160-262) on one rank: a Solver
+    (a context of the library) per level and the transfers of aither_amd.case.multigrid between
+    them.  levels: (cases, transfers) of multigrid.build_levels, finest first.  The cycle
+    (V: 1 coarse visit, W: 2) is host logic over the library's phases and the agx_mg_* calls;
+    the same driver runs the product library and the test oracle."""
+
+    def __init__(self, api, cases, transfers, device=0, stream=None):
+        self.api = api
+        self.levels = [Solver(api, c, device=device, stream=stream) for c in cases]
+        self.transfers = []
+        for trs in transfers:
+            keep = []
+            for t in trs:
+                keep.append(dict(
+                    tc=np.ascontiguousarray(t.to_coarse, dtype=np.int32),
+                    vf=np.ascontiguousarray(t.vol_fac, dtype=np.float64),
+                    cf=np.ascontiguousarray(t.coeffs, dtype=np.float64)))
+            self.transfers.append(keep)
+        deck = cases[0].deck
+        self.case, self.cfg = cases[0], self.levels[0].cfg
+        self.cycle_index = {"V": 1, "W": 2}[deck.multigrid_cycle]   # input.cpp (mgCycleIndex_)
+        self.history = []
+        self.l2_first = None
+
+    # -- plumbing ----------------------------------------------------------
+    def close(self):
+        for s in self.levels:
+            s.close()
+
+    @property
+    def block_ids(self):
+        return self.levels[0].block_ids
+
+    def download(self, field, gb, level=0):
+        return self.levels[level].download(field, gb)
+
+    def _p(self, a, ctype):
+        return a.ctypes.data_as(C.POINTER(ctype))
+
+    def _boundary_and_residual(self, s, mm, cfl):
+        api = self.api
+        api.check(api.phase_bc_faces(s.ctx), "phase_bc_faces")
+        api.check(api.halo_swap_local(s.ctx, abi.HALO_STATE), "halo_swap_local")
+        api.check(api.phase_bc_edges(s.ctx), "phase_bc_edges")
+        api.check(api.phase_residual(s.ctx, mm, cfl), "phase_residual")
+
+    # -- linearSolver::Relax (linearSolver.cpp:430-470, :509-536) ---------------
+    def relax(self, lev, sweeps):
+        api, s = self.api, self.levels[lev]
+        lusgs = s.cfg.matrix_solver in (abi.SOLVER["lusgs"], abi.SOLVER["blusgs"])
+        for ii in range(sweeps):
+            api.check(api.halo_swap_local(s.ctx, abi.HALO_UPDATE), "halo_swap_local")
+            api.check(api.phase_relax_forward(s.ctx, ii), "relax_forward")
+            if lusgs:
+                api.check(api.halo_swap_local(s.ctx, abi.HALO_UPDATE), "halo_swap_local")
+                api.check(api.phase_relax_backward(s.ctx, ii), "relax_backward")
+        api.check(api.halo_swap_local(s.ctx, abi.HALO_UPDATE), "halo_swap_local")
+        mres = C.c_double(0.0)
+        api.check(api.mg_matrix_residual(s.ctx, C.byref(mres)), "mg_matrix_residual")
+        return mres.value
+
+    # -- gridLevel::Restriction (gridLevel.cpp:538-595) --------------------------
+    def restriction(self, fl, mm, cfl):
+        api, f, c = self.api, self.levels[fl], self.levels[fl + 1]
+        trs = self.transfers[fl]
+        for gb, bid in f.block_ids.items():
+            t = trs[gb]
+            api.check(api.mg_restrict(f.ctx, c.ctx, bid, 0, self._p(t["tc"], C.c_int32),
+                                      self._p(t["vf"], C.c_double)), "mg_restrict state")
+            if mm == 0:          # need the solution at time n for the linear solvers
+                api.check(api.store_time_n(c.ctx, 0), "store_time_n")
+        self._boundary_and_residual(c, mm, cfl)
+        api.check(api.mg_invert_diagonal(c.ctx), "mg_invert_diagonal")
+        for gb, bid in f.block_ids.items():
+            t = trs[gb]
+            api.check(api.mg_restrict(f.ctx, c.ctx, bid, 1, self._p(t["tc"], C.c_int32),
+                                      self._p(t["vf"], C.c_double)), "mg_restrict update")
+        api.check(api.halo_swap_local(c.ctx, abi.HALO_UPDATE), "halo_swap_local")
+        for gb, bid in f.block_ids.items():
+            t = trs[gb]
+            api.check(api.mg_restrict(f.ctx, c.ctx, bid, 2, self._p(t["tc"], C.c_int32),
+                                      None), "mg_restrict forcing")
+
+    # -- mgSolution::CycleAtLevel (mgSolution.cpp:160-205) ------------------------
+    def cycle(self, fl, mm, cfl):
+        api = self.api
+        sweeps_all = self.cfg.matrix_sweeps
+        if fl == len(self.levels) - 1:
+            return self.relax(fl, sweeps_all)
+        sweeps = max(sweeps_all // 2, 1)
+        self.relax(fl, sweeps)
+        cl = fl + 1
+        self.restriction(fl, mm, cfl)
+        api.check(api.mg_save_update(self.levels[cl].ctx), "mg_save_update")
+        for _ in range(self.cycle_index):
+            self.cycle(cl, mm, cfl)
+        f, c = self.levels[fl], self.levels[cl]
+        for gb, bid in f.block_ids.items():
+            t = self.transfers[fl][gb]
+            api.check(api.mg_prolong(c.ctx, f.ctx, bid, self._p(t["tc"], C.c_int32),
+                                     self._p(t["cf"], C.c_double)), "mg_prolong")
+        return self.relax(fl, sweeps)
+
+    # -- mgSolution::Iterate / ImplicitUpdate (mgSolution.cpp:207-262) -------------
+    def iterate(self, mm, cfl):
+        api, f = self.api, self.levels[0]
+        l2 = np.zeros(self.cfg.n_eq)
+        linf = abi.Linf()
+        self._boundary_and_residual(f, mm, cfl)
+        api.check(api.phase_implicit_begin(f.ctx), "phase_implicit_begin")
+        mres = self.cycle(0, mm, cfl)
+        api.check(api.phase_implicit_update(f.ctx, mm, l2.ctypes.data_as(abi.c_dp),
+                                            C.byref(linf)), "implicit_update")
+        for s in self.levels[1:]:      # ResetDiagonal on every level (mgSolution.cpp:236-239)
+            api.check(api.mg_reset_diagonal(s.ctx), "mg_reset_diagonal")
+        return l2, linf, mres
+
+    normalized = Solver.normalized
+
+    def step(self, nn):
+        d = self.case.deck
+        cfl = d.cfl(nn)
+        for s in self.levels:          # mgSolution::StoreOldSolution: every level
+            s.store_time_n(nn)
+        out = None
+        for mm in range(d.nonlinear_iterations):
+            l2, linf, mres = self.iterate(mm, cfl)
+            total = self.case.total_cells
+            mres = math.sqrt(mres / (total * self.cfg.n_eq))
+            out = dict(nn=nn, mm=mm, l2=np.sqrt(l2), norm=self.normalized(l2, nn, mm),
+                       linf=(linf.linf, linf.block, linf.i, linf.j, linf.k, linf.eqn),
+                       matrix=mres)
+            self.history.append(out)
+        return out
+
+    def run(self, iterations):
+        out = None
+        for nn in range(iterations):
+            out = self.step(nn)
+        return out

@@ -68,6 +68,9 @@ typedef struct {
   double *dt;            /* dt_ [cells]                         */
   double *consn, *consnm1; /* consVarsN_, consVarsNm1_ [cells][NEQM] */
   double *x, *xold;      /* linearSolver x_ [cells_g][NEQM]      */
+  /* multigrid (null on a level without): mgForcing_ [cells][NEQM], the matrix residual of
+   * the last Relax [cells][NEQM], coarseDu [cells_g][NEQM] */
+  double *forcing, *mres, *xsave;
   double *a, *ainv;      /* linearSolver a_, aInv_ (scalar) [cells] */
   double *am, *aminv;    /* block-matrix solvers: 5 x 5 per cell, row major (matMultiArray3d) */
   /* rans: turbulence part of specRadius_ / a_ / aInv_ (uncoupledScalar) [cells];
@@ -2292,8 +2295,16 @@ static void update_block(ora_ctx *c, blk_t *b, int rr, double *l2,
 /* implicit                                                                  */
 /* procBlock::SolDeltaNCoeff / SolDeltaMmN / SolDeltaNm1 procBlock.cpp:1010-1035
  * and the 'b' term of linearSolver.cpp:370-374 */
+/* (forcing: the multigrid forcing term is part of b in the LU-SGS sweeps,
+ * linearSolver.cpp:377, :422; DPLUR adds it to b, :503; AXmB has none, :72-75) */
+static void rhs_b_f(const ora_ctx *c, const blk_t *b, int i, int j, int k, int forcing,
+                    double *out);
 static void rhs_b(const ora_ctx *c, const blk_t *b, int i, int j, int k,
                   double *out) {
+  rhs_b_f(c, b, i, j, k, 0, out);
+}
+static void rhs_b_f(const ora_ctx *c, const blk_t *b, int i, int j, int k, int forcing,
+                    double *out) {
   const long p = PI(b, i, j, k), q = CI(b, i, j, k);
   const double thetaInv = 1.0 / c->cfg.theta;
   const double coeffN =
@@ -2307,7 +2318,8 @@ static void rhs_b(const ora_ctx *c, const blk_t *b, int i, int j, int k,
     const double nm1 =
         multi ? coeffNm1 * (b->consn[NEQ * p + e] - b->consnm1[NEQ * p + e])
               : 0.0;
-    out[e] = -thetaInv * b->resid[NEQ * p + e] + 0.0 + nm1 - mmn;
+    const double f = forcing && b->forcing ? b->forcing[NEQ * p + e] : 0.0;
+    out[e] = -thetaInv * b->resid[NEQ * p + e] + f + nm1 - mmn;
   }
 }
 
@@ -2446,7 +2458,9 @@ static void apply_ainv(const ora_ctx *c, const blk_t *b, long p, const double *v
     for (int e = NF; e < NEQ; ++e) out[e] = v[e] * b->ainv_t[p];   /* turbulence part */
   }
 }
-static int implicit_begin(ora_ctx *c, blk_t *b) {
+static int implicit_begin_x(ora_ctx *c, blk_t *b, int init_x);
+static int implicit_begin(ora_ctx *c, blk_t *b) { return implicit_begin_x(c, b, 1); }
+static int implicit_begin_x(ora_ctx *c, blk_t *b, int init_x) {
   int singular = 0;
 #pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS) reduction(|:singular)
   for (int k = 0; k < b->nk; ++k)
@@ -2485,6 +2499,7 @@ static int implicit_begin(ora_ctx *c, blk_t *b) {
         }
       }
   if (singular) return fail("Singular matrix in Gauss-Jordan elimination!");
+  if (!init_x) return 0;      /* (a coarse multigrid level: x is the restricted one) */
   if (requires_init(c)) {
 #pragma omp parallel for schedule(static) if (b->ncell >= OMP_MIN_CELLS)
     for (int k = 0; k < b->nk; ++k)
@@ -2517,7 +2532,7 @@ static void lusgs_forward(ora_ctx *c, blk_t *b, int sweep) {
           implicit_upper(c, b, i, j, k, b->x, U);
           for (int e = 0; e < NEQ; ++e) off[e] -= U[e];
         }
-        rhs_b(c, b, i, j, k, rb);
+        rhs_b_f(c, b, i, j, k, 1, rb);
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
         double v[NEQM];
         for (int e = 0; e < NEQ; ++e) v[e] = rb[e] + off[e];
@@ -2538,7 +2553,7 @@ static void lusgs_backward(ora_ctx *c, blk_t *b, int sweep) {
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
         if (sweep > 0 || requires_init(c)) {
           implicit_lower(c, b, i, j, k, b->x, L);
-          rhs_b(c, b, i, j, k, rb);
+          rhs_b_f(c, b, i, j, k, 1, rb);
           double v[NEQM];
           for (int e = 0; e < NEQ; ++e) v[e] = rb[e] + L[e] - U[e];
           apply_ainv(c, b, p, v, b->x + NEQ * q);
@@ -2563,7 +2578,8 @@ static void dplur_sweep(ora_ctx *c, blk_t *b) {
         rhs_b(c, b, i, j, k, rb);
         const long p = PI(b, i, j, k), q = CI(b, i, j, k);
         double v[NEQM];
-        for (int e = 0; e < NEQ; ++e) v[e] = rb[e] + 0.0 + off[e];
+        for (int e = 0; e < NEQ; ++e)
+          v[e] = rb[e] + (b->forcing ? b->forcing[NEQ * p + e] : 0.0) + off[e];
         apply_ainv(c, b, p, v, b->x + NEQ * q);
       }
 }
@@ -2592,7 +2608,8 @@ static void matrix_residual(ora_ctx *c, blk_t *b, double *sumsq, long *size) {
         }
         for (int e = 0; e < NEQ; ++e) {
           const double axmb = ax[e] - off[e] - rb[e];
-          const double r = 0.0 - axmb;
+          const double r = (b->forcing ? b->forcing[NEQ * p + e] : 0.0) - axmb;
+          if (b->mres) b->mres[NEQ * p + e] = r;
           part[k] += r * r;
           opart[k] += ax[e] * ax[e] + off[e] * off[e] + rb[e] * rb[e];
         }
@@ -2619,6 +2636,7 @@ int ora_ctx_create(int device, int rank, ora_ctx **out) {
   return 0;
 }
 static void free_blk(blk_t *b) {
+  free(b->forcing); free(b->mres); free(b->xsave);
   double **ptrs[] = {&b->state, &b->fa[0], &b->fa[1], &b->fa[2], &b->vol,
                      &b->center, &b->wid[0], &b->wid[1], &b->wid[2],
                      &b->wdist, &b->temp, &b->visc, &b->velgrad, &b->grad18, &b->resid,
@@ -3118,6 +3136,181 @@ int ora_field_upload(ora_ctx *c, int id, int field, const double *in) {
 }
 
 /* procBlock::AssignSolToTimeN / AssignSolToTimeNm1 procBlock.cpp:1037-1054 */
+/* ---- geometric multigrid ---------------------------------------------------------------- */
+static int mg_blocks(ora_ctx *f, ora_ctx *cz, int blk, blk_t **bf, blk_t **bc) {
+  if (!f || !cz || blk < 0 || blk >= f->nblk || blk >= cz->nblk) return fail("mg: bad block %d", blk);
+  *bf = &f->blk[blk];
+  *bc = &cz->blk[blk];
+  return 0;
+}
+/* BlockRestriction procBlock.hpp:636-690: the coarse array zeroed, then every fine cell in
+ * k, j, i order added to its coarse cell */
+int ora_mg_restrict(ora_ctx *f, ora_ctx *cz, int blk, int what, const int32_t *tc,
+                    const double *vf) {
+  blk_t *bf, *bc;
+  if (mg_blocks(f, cz, blk, &bf, &bc)) return 1;
+  if (what == AGX_MG_STATE) {
+    if (!vf) return fail("mg_restrict: volume weights missing");
+    memset(bc->state, 0, sizeof(double) * NEQ * bc->ncell_g);
+    for (int k = 0; k < bf->nk; ++k)
+      for (int j = 0; j < bf->nj; ++j)
+        for (int i = 0; i < bf->ni; ++i) {
+          const long p = PI(bf, i, j, k);
+          const long qc = CI(bc, tc[3 * p], tc[3 * p + 1], tc[3 * p + 2]);
+          const long qf = CI(bf, i, j, k);
+          for (int e = 0; e < NEQ; ++e)
+            bc->state[NEQ * qc + e] = bc->state[NEQ * qc + e] + vf[p] * bf->state[NEQ * qf + e];
+        }
+    if (NEQ > NF) return fail("mg_restrict: multigrid is built for the 5-equation sets");
+    return 0;
+  }
+  if (what == AGX_MG_UPDATE) {
+    if (!vf) return fail("mg_restrict: volume weights missing");
+    memset(bc->x, 0, sizeof(double) * NEQ * bc->ncell_g);
+    for (int k = 0; k < bf->nk; ++k)
+      for (int j = 0; j < bf->nj; ++j)
+        for (int i = 0; i < bf->ni; ++i) {
+          const long p = PI(bf, i, j, k);
+          const long qc = CI(bc, tc[3 * p], tc[3 * p + 1], tc[3 * p + 2]);
+          const long qf = CI(bf, i, j, k);
+          for (int e = 0; e < NEQ; ++e)
+            bc->x[NEQ * qc + e] = bc->x[NEQ * qc + e] + vf[p] * bf->x[NEQ * qf + e];
+        }
+    return 0;
+  }
+  if (what != AGX_MG_FORCING) return fail("mg_restrict: bad selector %d", what);
+  if (!bf->mres) return fail("mg_restrict: the fine level has no matrix residual yet");
+  if (!bc->forcing) bc->forcing = (double *)calloc((size_t)NEQ * bc->ncell, sizeof(double));
+  double *fo = bc->forcing;
+  memset(fo, 0, sizeof(double) * NEQ * bc->ncell);
+  for (int k = 0; k < bf->nk; ++k)
+    for (int j = 0; j < bf->nj; ++j)
+      for (int i = 0; i < bf->ni; ++i) {
+        const long p = PI(bf, i, j, k);
+        const long pc = PI(bc, tc[3 * p], tc[3 * p + 1], tc[3 * p + 2]);
+        for (int e = 0; e < NEQ; ++e) fo[NEQ * pc + e] = fo[NEQ * pc + e] + bf->mres[NEQ * p + e];
+      }
+  /* + A x - b of the coarse level (linearSolver::AXmB :58-90; gridLevel.cpp:579-589) */
+  for (int k = 0; k < bc->nk; ++k)
+    for (int j = 0; j < bc->nj; ++j)
+      for (int i = 0; i < bc->ni; ++i) {
+        double off[NEQM], U[NEQM], rb[NEQM], ax[NEQM];
+        implicit_lower(cz, bc, i, j, k, bc->x, off);
+        implicit_upper(cz, bc, i, j, k, bc->x, U);
+        for (int e = 0; e < NEQ; ++e) off[e] -= U[e];
+        rhs_b(cz, bc, i, j, k, rb);
+        const long p = PI(bc, i, j, k), q = CI(bc, i, j, k);
+        if (is_block(cz)) {
+          mat_vec(bc->am + NJ * p, bc->x + NEQ * q, ax);
+          for (int e = NF; e < NEQ; ++e) ax[e] = bc->am_t[2 * p + e - NF] * bc->x[NEQ * q + e];
+        } else {
+          for (int e = 0; e < NF; ++e) ax[e] = bc->x[NEQ * q + e] * bc->a[p];
+          for (int e = NF; e < NEQ; ++e) ax[e] = bc->x[NEQ * q + e] * bc->a_t[p];
+        }
+        for (int e = 0; e < NEQ; ++e) fo[NEQ * p + e] = (ax[e] - off[e] - rb[e]) + fo[NEQ * p + e];
+      }
+  return 0;
+}
+int ora_mg_matrix_residual(ora_ctx *c, double *mr) {
+  double sumsq = 0.0;
+  long size = 0;
+  c->mres_opsq = 0.0;
+  for (int n = 0; n < c->nblk; ++n) {
+    blk_t *b = &c->blk[n];
+    if (!b->mres) b->mres = (double *)calloc((size_t)NEQ * b->ncell, sizeof(double));
+    matrix_residual(c, b, &sumsq, &size);
+  }
+  c->mres_sumsq = sumsq;
+  *mr = size > 0 ? sumsq / (double)size : 0.0;
+  return 0;
+}
+int ora_mg_invert_diagonal(ora_ctx *c) {
+  for (int n = 0; n < c->nblk; ++n)
+    if (implicit_begin_x(c, &c->blk[n], 0)) return 1;
+  return 0;
+}
+/* gridLevel::ResetDiagonal gridLevel.cpp:408-412 (mgSolution::ImplicitUpdate resets every
+ * level when the iteration ends, mgSolution.cpp:236-239; the finest one inside
+ * ora_phase_implicit_update) */
+int ora_mg_reset_diagonal(ora_ctx *c) {
+  for (int n = 0; n < c->nblk; ++n) {
+    blk_t *b = &c->blk[n];
+    memset(b->a, 0, sizeof(double) * b->ncell);
+    memset(b->a_t, 0, sizeof(double) * b->ncell);
+    memset(b->am, 0, sizeof(double) * NJ * b->ncell);
+    memset(b->am_t, 0, sizeof(double) * 2 * b->ncell);
+  }
+  return 0;
+}
+int ora_mg_save_update(ora_ctx *c) {
+  for (int n = 0; n < c->nblk; ++n) {
+    blk_t *b = &c->blk[n];
+    if (!b->xsave) b->xsave = (double *)calloc((size_t)NEQ * b->ncell_g, sizeof(double));
+    memcpy(b->xsave, b->x, sizeof(double) * NEQ * b->ncell_g);
+  }
+  return 0;
+}
+/* SubtractFromUpdate (linearSolver.cpp:120-126), BlockProlongation (gridLevel.hpp:159-214)
+ * with ConvertCellToNode(coarse, ignoreEdge, ignoreGhosts) (utility.hpp:186-330),
+ * AddToUpdate (linearSolver.cpp:128-134) */
+int ora_mg_prolong(ora_ctx *cz, ora_ctx *f, int blk, const int32_t *tc, const double *cf) {
+  blk_t *bf, *bc;
+  if (mg_blocks(f, cz, blk, &bf, &bc)) return 1;
+  if (!bc->xsave) return fail("mg_prolong: no saved update on the coarse level");
+  for (long q = 0; q < NEQ * bc->ncell_g; ++q) bc->x[q] -= bc->xsave[q];
+  const int ni = bc->ni, nj = bc->nj, nk = bc->nk;
+  const long nn = (long)(ni + 1) * (nj + 1) * (nk + 1);
+  double *nd = (double *)calloc((size_t)NEQ * nn, sizeof(double));
+#define ND(i, j, k) (nd + NEQ * (((long)(k) * (nj + 1) + (j)) * (ni + 1) + (i)))
+  for (int k = 0; k < nk; ++k)
+    for (int j = 0; j < nj; ++j)
+      for (int i = 0; i < ni; ++i) {
+        const double *v = bc->x + NEQ * CI(bc, i, j, k);
+        /* the order of utility.hpp:286-311 */
+        static const int o[8][3] = {{0, 0, 0}, {0, 1, 0}, {0, 1, 1}, {0, 0, 1},
+                                    {1, 0, 0}, {1, 1, 0}, {1, 1, 1}, {1, 0, 1}};
+        for (int m = 0; m < 8; ++m) {
+          double *t = ND(i + o[m][0], j + o[m][1], k + o[m][2]);
+          for (int e = 0; e < NEQ; ++e) t[e] += v[e];
+        }
+      }
+  for (int k = 0; k <= nk; ++k)
+    for (int j = 0; j <= nj; ++j)
+      for (int i = 0; i <= ni; ++i) {
+        const int xi = i == 0 || i == ni, xj = j == 0 || j == nj, xk = k == 0 || k == nk;
+        /* AtInteriorCorner / AtInteriorEdge of the node array (multiArray3d.hpp:1595-1683);
+         * no ghost cells: corner 1, edge 1/2, the rest 1/8 */
+        const double fac = (xi && xj && xk) ? 1.0 : ((xj && xk) || (xi && xk) || (xi && xj)) ? 0.5 : 0.125;
+        double *t = ND(i, j, k);
+        for (int e = 0; e < NEQ; ++e) t[e] *= fac;
+      }
+  for (int k = 0; k < bf->nk; ++k)
+    for (int j = 0; j < bf->nj; ++j)
+      for (int i = 0; i < bf->ni; ++i) {
+        const long p = PI(bf, i, j, k);
+        const int ci = tc[3 * p], cj = tc[3 * p + 1], ck = tc[3 * p + 2];
+        const double *w = cf + 7 * p;
+        const double *d0 = ND(ci, cj, ck), *d1 = ND(ci + 1, cj, ck), *d2 = ND(ci, cj + 1, ck),
+                     *d3 = ND(ci + 1, cj + 1, ck), *d4 = ND(ci, cj, ck + 1),
+                     *d5 = ND(ci + 1, cj, ck + 1), *d6 = ND(ci, cj + 1, ck + 1),
+                     *d7 = ND(ci + 1, cj + 1, ck + 1);
+        double *xf = bf->x + NEQ * CI(bf, i, j, k);
+        for (int e = 0; e < NEQ; ++e) {
+          /* TrilinearInterp utility.hpp:356-372, LinearInterp :341-344 */
+          const double d04 = (1.0 - w[0]) * d0[e] + w[0] * d4[e];
+          const double d15 = (1.0 - w[1]) * d1[e] + w[1] * d5[e];
+          const double d26 = (1.0 - w[2]) * d2[e] + w[2] * d6[e];
+          const double d37 = (1.0 - w[3]) * d3[e] + w[3] * d7[e];
+          const double d0415 = (1.0 - w[4]) * d04 + w[4] * d15;
+          const double d2637 = (1.0 - w[5]) * d26 + w[5] * d37;
+          xf[e] += (1.0 - w[6]) * d0415 + w[6] * d2637;
+        }
+      }
+#undef ND
+  free(nd);
+  return 0;
+}
+
 int ora_store_time_n(ora_ctx *c, int also_nm1) {
   c->have_time_n = 1;
   for (int n = 0; n < c->nblk; ++n) {

@@ -43,6 +43,14 @@ int ora_plot3d_metrics(ora_ctx *ctx, int ni, int nj, int nk, const double *nodes
                        double *fcenter_k);
 int ora_nearest_wall_distance(ora_ctx *ctx, int64_t ncell, const double *cell_centres,
                               int64_t nwall, const double *wall_points, double *dist);
+int ora_mg_restrict(ora_ctx *fine, ora_ctx *coarse, int blk, int what,
+                    const int32_t *to_coarse, const double *vol_fac);
+int ora_mg_matrix_residual(ora_ctx *ctx, double *mean_square);
+int ora_mg_invert_diagonal(ora_ctx *ctx);
+int ora_mg_save_update(ora_ctx *ctx);
+int ora_mg_reset_diagonal(ora_ctx *ctx);
+int ora_mg_prolong(ora_ctx *coarse, ora_ctx *fine, int blk, const int32_t *to_coarse,
+                   const double *coeffs);
 int ora_store_time_n(ora_ctx *ctx, int also_nm1);
 int ora_iterate(ora_ctx *ctx, int mm, double cfl, double *l2, agx_linf *linf,
                 double *matrix_resid);

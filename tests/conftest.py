@@ -45,3 +45,19 @@ def agx():
 def golden_case(name):
     from aither_amd.case.builder import build_case
     return build_case(os.path.join(GOLDEN, "cases", name, name + ".inp"))
+
+
+def golden_solver(api, name):
+    """A Solver of a golden case -- a MultigridSolver over its grid levels where the deck
+    asks for more than one (transonicBump)."""
+    from aither_amd.case import builder, geometry, multigrid
+    from aither_amd.case.inputfile import parse_input
+    from aither_amd.solver import MultigridSolver, Solver
+    base = os.path.join(GOLDEN, "cases", name)
+    deck = parse_input(os.path.join(base, name + ".inp"))
+    if deck.multigrid_levels == 1:
+        return Solver(api, golden_case(name))
+    coords = geometry.read_plot3d(os.path.join(base, deck.grid_name + ".xyz"), deck.l_ref)
+    cases, transfers = multigrid.build_levels(deck, coords, deck.multigrid_levels,
+                                              builder.build_case)
+    return MultigridSolver(api, cases, transfers)

@@ -6,7 +6,7 @@ grid, for one case a point cloud of the initial state -- and, inside
 testCases/regressionTests.py, the normalised L2 residuals its own binary must reproduce
 after a fixed number of iterations.  This script
 
-  * copies the DATA files of the eleven cases that lie inside the hot path
+  * copies the DATA files of the twelve cases that lie inside the hot path
     (tests/golden/cases/<case>/) -- nothing of the reference's code is copied;
   * transcribes their truth vectors, iteration counts, ignored columns and the line of
     regressionTests.py each vector stands on (regression_truths.json: `truth`,
@@ -21,8 +21,8 @@ after a fixed number of iterations.  This script
                                                   what the reference yields (default)
   python tests/golden/make_fixtures.py --write    (re)generate the tree
 
-Cases NOT taken: transonicBump (multigrid), thermallyPerfect, supersonicMixing,
-dissociation (multi-species / thermally perfect / chemistry) -- outside the path.
+Cases NOT taken: thermallyPerfect, supersonicMixing, dissociation (multi-species /
+thermally perfect / chemistry) -- outside the path.
 """
 import filecmp
 import json
@@ -39,7 +39,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = {
     "supersonicWedge": 1, "subsonicCylinder": 1, "multiblockCylinder": 2, "shockTube": 1,
     "viscousFlatPlate": 1, "couette": 1, "rae2822": 1, "turbFlatPlate": 1, "wallLaw": 1,
-    "convectingVortex": 1, "uniformFlow": None,      # None: no truth taken (see above)
+    "convectingVortex": 1, "transonicBump": 1,
+    "uniformFlow": None,      # None: no truth taken (see above)
 }
 ITER_VARS = {"numIterations": 100, "numIterationsShort": 20}
 UNIFORMFLOW_EDITS = [        # (regex, replacement) applied to the reference's deck

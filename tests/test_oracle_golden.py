@@ -3,8 +3,9 @@
 The reference's tests (testCases/regressionTests.py) run each case for a fixed
 number of iterations and compare the last line of <case>.resid with hard-coded
 normalised L2 residuals to 1 %.  The same inputs (grid + .inp, copied as data
-under tests/golden/cases) are run here through the oracle; eight cases
-reproduce every printed digit (5 significant figures), couette and
+under tests/golden/cases) are run here through the oracle; nine cases
+reproduce every printed digit (5 significant figures; transonicBump through the
+three-level W cycle of the multigrid driver), couette and
 convectingVortex agree to 1e-3 or better, inside the reference's own 1 %
 tolerance.
 """
@@ -13,7 +14,7 @@ import os
 
 import pytest
 
-from conftest import GOLDEN, golden_case
+from conftest import GOLDEN, golden_case, golden_solver
 from aither_amd.solver import Solver
 
 with open(os.path.join(GOLDEN, "regression_truths.json")) as fh:
@@ -23,8 +24,7 @@ with open(os.path.join(GOLDEN, "regression_truths.json")) as fh:
 @pytest.mark.parametrize("name", sorted(TRUTH))
 def test_oracle_reproduces_reference_truth(oracle, name):
     spec = TRUTH[name]
-    case = golden_case(name)
-    sol = Solver(oracle, case)
+    sol = golden_solver(oracle, name)
     out = sol.run(spec["iterations"])
     got = out["norm"]
     for idx, (g, t) in enumerate(zip(got, spec["truth"])):
@@ -90,4 +90,4 @@ def test_golden_tree_is_reproduced_by_its_script():
     out = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_fixtures.py")],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "11 case directories" in out.stdout and "10 truth vectors" in out.stdout
+    assert "12 case directories" in out.stdout and "11 truth vectors" in out.stdout
