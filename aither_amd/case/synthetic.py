@@ -144,6 +144,27 @@ def stacked_blocks_case(n=(16, 16, 16), nblocks=2, axis="k", stretch=1.0,
                         bcs=None, amplitude=0.05, ranks=None, setup=None, **deck_kw):
     """nblocks boxes stacked along `axis`, joined by interblock connections
     (orientation 1, lower <-> upper)."""
+    deck, coords = _stacked(n, nblocks, axis, stretch, bcs, deck_kw)
+    case = _b.build_case(None, deck=deck, coords=coords, ranks=ranks, setup=setup)
+    if amplitude:
+        perturbed_state(case, amplitude)
+    return case
+
+
+def multigrid_levels(n=(16, 16, 16), nblocks=1, axis="k", levels=2, cycle="V", stretch=1.0,
+                     bcs=None, amplitude=0.05, **deck_kw):
+    """(cases, transfers) of aither_amd.case.multigrid.build_levels for nblocks boxes stacked
+    along `axis` (one box: no connections); the finest level's state is perturbed."""
+    from . import multigrid as _mg
+    deck, coords = _stacked(n, nblocks, axis, stretch, bcs, deck_kw)
+    deck.multigrid_cycle = cycle
+    cases, transfers = _mg.build_levels(deck, coords, levels, _b.build_case)
+    if amplitude:
+        perturbed_state(cases[0], amplitude)
+    return cases, transfers
+
+
+def _stacked(n, nblocks, axis, stretch, bcs, deck_kw):
     ni, nj, nk = n
     deck = make_deck(**deck_kw)
     d = "ijk".index(axis)
@@ -170,10 +191,7 @@ def stacked_blocks_case(n=(16, 16, 16), nblocks=2, axis="k", stretch=1.0,
             blk_bcs[hi_s] = ("interblock", 1000 * lo_s + (b + 1))
         all_bcs.append(box_surfaces(ni, nj, nk, blk_bcs))
     deck.bcs = all_bcs
-    case = _b.build_case(None, deck=deck, coords=coords, ranks=ranks, setup=setup)
-    if amplitude:
-        perturbed_state(case, amplitude)
-    return case
+    return deck, coords
 
 
 def cube_blocks_case(n=(8, 8, 8), splits=(2, 2, 2), bcs=None, amplitude=0.05,
