@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Time of a multigrid iteration against a single-grid one on the GPU (synthetic box, Euler,
+MUSCL + vanAlbada + Roe, scalar DPLUR 4 sweeps): python tools/mg_timing.py [n] [levels] [cycle].
+Under `rocprofv3 --kernel-trace --stats` the k_mg_* rows are the transfer kernels."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import aither_amd
+from aither_amd.case import synthetic
+from aither_amd.solver import MultigridSolver
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+levels = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+cycle = sys.argv[3] if len(sys.argv) > 3 else "V"
+api = aither_amd.load(5)
+kw = dict(n=(n, n, n), stretch=1.02, time_integration="implicitEuler", matrix_solver="dplur",
+          matrix_sweeps=4, cfl=50.0, amplitude=0.02)
+for lev in (1, levels):
+    t0 = time.time()
+    cases, trs = synthetic.multigrid_levels(levels=lev, cycle=cycle, **kw)
+    s = MultigridSolver(api, cases, trs)
+    tb = time.time() - t0
+    for nn in range(3):
+        s.step(nn)
+    api.check(api.sync(s.levels[0].ctx), "sync")
+    t0 = time.time()
+    its = 10
+    for nn in range(3, 3 + its):
+        out = s.step(nn)
+    api.check(api.sync(s.levels[0].ctx), "sync")
+    dt = (time.time() - t0) / its
+    print(f"levels {lev} ({cycle}): {dt * 1e3:.2f} ms per iteration, matrix residual {out['matrix']:.3e}, "
+          f"L2 {out['norm'][0]:.3e} (set-up {tb:.1f} s)", flush=True)
+    s.close()
