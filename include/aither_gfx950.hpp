@@ -14,13 +14,17 @@
 //   mgSolution::StoreOldSolution (:103-114)     hotPath::StoreOldSolution
 //   mgSolution::Iterate (:246-269)              hotPath::Iterate
 //   GetFinestGridLevel pack (procBlock.cpp:4491) hotPath::Download
+//   mgSolution with several levels (:128-262)   multigrid::{StoreOldSolution, Iterate,
+//                                               CycleAtLevel, Restriction, Relax, Prolongation}
 //
 // AGX_SYMBOL_PREFIX lets the test suite build the same driver against the CPU
 // oracle (prefix ora_), which exports the identical entry points.
 #ifndef AITHER_GFX950_HPP
 #define AITHER_GFX950_HPP
+#include <algorithm>
 #include <cstdlib>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 #include "aither_gfx950.h"
@@ -168,6 +172,138 @@ class hotPath {
     Check(AGX_SYM(iterate)(ctx_, mm, cfl, residL2.data(), &linf, &matrixResid),
           "hotPath::Iterate");
     residLinf.UpdateMax(linf.linf, linf.block, linf.i, linf.j, linf.k, linf.eqn);
+    return matrixResid;
+  }
+
+  friend class multigrid;
+};
+
+// mgSolution with more than one grid level (mgSolution.cpp:128-262) on one rank: a hotPath
+// per gridLevel (finest first; every level configured, given its coarsened blocks and
+// surfaces -- procBlock::GetCoarseMeshAndBCs -- and finalized by the caller) and, per level
+// but the coarsest and per block, the arrays gridLevel::Coarsen builds: toCoarse_ (int32
+// triples), volWeightFactor_, prolongCoeffs_ (7 doubles), all per physical fine cell in
+// k-j-i order.  The cycle is the reference's; what crosses between two levels runs in the
+// library (agx_mg_*).  Scalar DPLUR.
+class multigrid {
+  struct transfer {
+    std::vector<int32_t> toCoarse;
+    std::vector<double> volFac, coeffs;
+  };
+  std::vector<std::unique_ptr<hotPath>> solution_;
+  std::vector<std::vector<transfer>> transfer_;   // [fine level][block]
+  int mgCycleIndex_ = 1;                          // V: 1, W: 2
+  int matrixSweeps_ = 1;
+  bool lusgs_ = false;
+
+  static void Check(int rc, const char *what) { hotPath::Check(rc, what); }
+  AGX_CAT(AGX_SYMBOL_PREFIX, ctx) *Ctx(int ll) const { return solution_[ll]->ctx_; }
+
+  // gridLevel::GetBoundaryConditions, CalcResidual, CalcTimeStep
+  void BoundaryAndResidual(int ll, int mm, double cfl) {
+    Check(AGX_SYM(phase_bc_faces)(Ctx(ll)), "multigrid (phase_bc_faces)");
+    Check(AGX_SYM(halo_swap_local)(Ctx(ll), AGX_HALO_STATE), "multigrid (halo_swap_local)");
+    Check(AGX_SYM(phase_bc_edges)(Ctx(ll)), "multigrid (phase_bc_edges)");
+    Check(AGX_SYM(phase_residual)(Ctx(ll), mm, cfl), "multigrid (phase_residual)");
+  }
+
+ public:
+  multigrid(int cycleIndex, const agx_config &cfg)
+      : mgCycleIndex_(cycleIndex), matrixSweeps_(cfg.matrix_sweeps),
+        lusgs_(cfg.matrix_solver == AGX_SOLVER_LUSGS || cfg.matrix_solver == AGX_SOLVER_BLUSGS) {}
+  int NumGridLevels() const { return static_cast<int>(solution_.size()); }
+  hotPath &Level(int ll) { return *solution_[ll]; }
+  // levels are added finest first
+  void AddLevel(std::unique_ptr<hotPath> level) {
+    solution_.push_back(std::move(level));
+    transfer_.emplace_back();
+  }
+  // the transfer arrays of block `blk` of level `fl` towards level fl + 1 (blocks in order)
+  void AddTransfer(int fl, std::vector<int32_t> toCoarse, std::vector<double> volFac,
+                   std::vector<double> coeffs) {
+    transfer_[fl].push_back(transfer{std::move(toCoarse), std::move(volFac), std::move(coeffs)});
+  }
+
+  // mgSolution::StoreOldSolution (:103-114): every level
+  void StoreOldSolution(bool alsoNm1) {
+    for (auto &sol : solution_) sol->StoreOldSolution(alsoNm1);
+  }
+  // linearSolver::Relax (linearSolver.cpp:430-470, :509-536); returns sum(r^2) / size
+  double Relax(int ll, int sweeps) {
+    for (int ii = 0; ii < sweeps; ++ii) {
+      Check(AGX_SYM(halo_swap_local)(Ctx(ll), AGX_HALO_UPDATE), "multigrid::Relax (SwapUpdate)");
+      Check(AGX_SYM(phase_relax_forward)(Ctx(ll), ii), "multigrid::Relax");
+      if (lusgs_) {
+        Check(AGX_SYM(halo_swap_local)(Ctx(ll), AGX_HALO_UPDATE), "multigrid::Relax (SwapUpdate)");
+        Check(AGX_SYM(phase_relax_backward)(Ctx(ll), ii), "multigrid::Relax");
+      }
+    }
+    Check(AGX_SYM(halo_swap_local)(Ctx(ll), AGX_HALO_UPDATE), "multigrid::Relax (SwapUpdate)");
+    double l2 = 0.0;
+    Check(AGX_SYM(mg_matrix_residual)(Ctx(ll), &l2), "multigrid::Relax (Residual)");
+    return l2;
+  }
+  // gridLevel::Restriction (gridLevel.cpp:538-595)
+  void Restriction(int fi, int mm, double cfl) {
+    const int ci = fi + 1;
+    const auto &tr = transfer_[fi];
+    for (size_t bb = 0; bb < tr.size(); ++bb) {
+      Check(AGX_SYM(mg_restrict)(Ctx(fi), Ctx(ci), static_cast<int>(bb), AGX_MG_STATE,
+                                 tr[bb].toCoarse.data(), tr[bb].volFac.data()),
+            "multigrid::Restriction (state)");
+      if (mm == 0) solution_[ci]->StoreOldSolution(false);
+    }
+    BoundaryAndResidual(ci, mm, cfl);
+    Check(AGX_SYM(mg_invert_diagonal)(Ctx(ci)), "multigrid::Restriction (InvertDiagonal)");
+    for (size_t bb = 0; bb < tr.size(); ++bb)
+      Check(AGX_SYM(mg_restrict)(Ctx(fi), Ctx(ci), static_cast<int>(bb), AGX_MG_UPDATE,
+                                 tr[bb].toCoarse.data(), tr[bb].volFac.data()),
+            "multigrid::Restriction (update)");
+    Check(AGX_SYM(halo_swap_local)(Ctx(ci), AGX_HALO_UPDATE), "multigrid::Restriction (SwapUpdate)");
+    for (size_t bb = 0; bb < tr.size(); ++bb)
+      Check(AGX_SYM(mg_restrict)(Ctx(fi), Ctx(ci), static_cast<int>(bb), AGX_MG_FORCING,
+                                 tr[bb].toCoarse.data(), nullptr),
+            "multigrid::Restriction (forcing)");
+  }
+  // SubtractFromUpdate + Prolongation (mgSolution.cpp:189-192)
+  void Prolongation(int ci) {
+    const auto &tr = transfer_[ci - 1];
+    for (size_t bb = 0; bb < tr.size(); ++bb)
+      Check(AGX_SYM(mg_prolong)(Ctx(ci), Ctx(ci - 1), static_cast<int>(bb),
+                                tr[bb].toCoarse.data(), tr[bb].coeffs.data()),
+            "multigrid::Prolongation");
+  }
+  // mgSolution::CycleAtLevel (:160-205)
+  double CycleAtLevel(int fl, int mm, double cfl) {
+    if (fl == NumGridLevels() - 1) return Relax(fl, matrixSweeps_);   // recursive base case
+    const int sweeps = std::max(matrixSweeps_ / 2, 1);
+    Relax(fl, sweeps);
+    const int cl = fl + 1;
+    Restriction(fl, mm, cfl);
+    Check(AGX_SYM(mg_save_update)(Ctx(cl)), "multigrid::CycleAtLevel (coarseDu)");
+    for (int ii = 0; ii < mgCycleIndex_; ++ii) CycleAtLevel(cl, mm, cfl);
+    Prolongation(cl);
+    return Relax(fl, sweeps);
+  }
+  // mgSolution::Iterate / ImplicitUpdate (:207-262); residL2 accumulated into, residLinf only
+  // replaced by a larger value, the return value as hotPath::Iterate
+  double Iterate(int mm, double cfl, residual &residL2, resid &residLinf) {
+    BoundaryAndResidual(0, mm, cfl);
+    Check(AGX_SYM(phase_implicit_begin)(Ctx(0)), "multigrid::Iterate (InvertDiagonal)");
+    const double matrixResid = CycleAtLevel(0, mm, cfl);
+    agx_linf linf;
+    linf.linf = residLinf.Linf();
+    linf.block = residLinf.Block();
+    linf.i = residLinf.ILoc();
+    linf.j = residLinf.JLoc();
+    linf.k = residLinf.KLoc();
+    linf.eqn = residLinf.Eqn();
+    linf.pad_ = 0;
+    Check(AGX_SYM(phase_implicit_update)(Ctx(0), mm, residL2.data(), &linf),
+          "multigrid::Iterate (UpdateBlocks)");
+    residLinf.UpdateMax(linf.linf, linf.block, linf.i, linf.j, linf.k, linf.eqn);
+    for (int ll = 1; ll < NumGridLevels(); ++ll)      // ResetDiagonal on every level
+      Check(AGX_SYM(mg_reset_diagonal)(Ctx(ll)), "multigrid::Iterate (ResetDiagonal)");
     return matrixResid;
   }
 };

@@ -188,3 +188,72 @@ def test_cpp_multirank_gpu(oracle, tmp_path, kind, world):
     staged through pinned host buffers (host_buffers = 1)"""
     _multirank("host_parity_agx", oracle, tmp_path, kind, world, exact=False)
 
+
+
+# ---- the multigrid cycle from C++ (aither_gfx950::multigrid) -------------------------------
+MG_KW = dict(n=(12, 10, 8), nblocks=2, axis="i", stretch=1.1, levels=3, cycle="W",
+             time_integration="implicitEuler", matrix_solver="dplur", matrix_sweeps=4, cfl=40.0)
+
+
+def write_multigrid_files(cases, transfers, tmp_path, n_steps):
+    files = []
+    for lev, case in enumerate(cases):
+        files.append(str(tmp_path / f"level{lev}.bin"))
+        write_case_file(case, files[-1], n_steps)
+    tf = str(tmp_path / "transfers.bin")
+    with open(tf, "wb") as f:
+        f.write(struct.pack("<2i", 0x3247474d, len(transfers)))
+        for trs in transfers:
+            f.write(struct.pack("<i", len(trs)))
+            for t in trs:
+                f.write(struct.pack("<q", t.vol_fac.size))
+                f.write(np.ascontiguousarray(t.to_coarse, dtype="<i4").tobytes())
+                f.write(np.ascontiguousarray(t.vol_fac, dtype="<f8").tobytes())
+                f.write(np.ascontiguousarray(t.coeffs, dtype="<f8").tobytes())
+    return tf, files
+
+
+def _run_mg(driver, cycle_index, tf, of, files):
+    subprocess.check_call([os.path.join(CPP, driver), str(cycle_index), tf, of] + files, timeout=300)
+
+
+def test_cpp_multigrid_oracle_matches_python_driver(oracle, tmp_path):
+    """mgSolution::CycleAtLevel written twice -- aither_gfx950::multigrid (C++, the reference's
+    language) and aither_amd.solver.MultigridSolver (Python) -- over the same library (the
+    oracle): three levels, W cycle, two blocks with a connection; bit for bit."""
+    from aither_amd.solver import MultigridSolver
+    build_drivers()
+    cases, transfers = synthetic.multigrid_levels(**MG_KW)
+    tf, files = write_multigrid_files(cases, transfers, tmp_path, 3)
+    of = str(tmp_path / "ora.bin")
+    _run_mg("host_multigrid_ora", 2, tf, of, files)
+    hist, states = read_output(cases[0], of, 3)
+    s = MultigridSolver(oracle, cases, transfers)
+    for nn in range(3):
+        for lev in s.levels:
+            lev.store_time_n(nn)
+        l2, linf, mres = s.iterate(0, cases[0].deck.cfl(nn))
+        assert np.array_equal(l2, hist[nn][0])
+        assert linf.linf == hist[nn][1] and mres == hist[nn][2]
+    for gb in range(2):
+        assert np.array_equal(s.download("state", gb), states[gb])
+    s.close()
+
+
+@pytest.mark.gpu
+def test_cpp_multigrid_gpu_vs_oracle(tmp_path):
+    """The C++ multigrid driver over libaither_gfx950.so against the same driver over the
+    oracle."""
+    build_drivers()
+    cases, transfers = synthetic.multigrid_levels(**MG_KW)
+    tf, files = write_multigrid_files(cases, transfers, tmp_path, 3)
+    _run_mg("host_multigrid_agx", 2, tf, str(tmp_path / "agx.bin"), files)
+    _run_mg("host_multigrid_ora", 2, tf, str(tmp_path / "ora.bin"), files)
+    hg, sg = read_output(cases[0], str(tmp_path / "agx.bin"), 3)
+    ho, so = read_output(cases[0], str(tmp_path / "ora.bin"), 3)
+    ng = cases[0].ng
+    for (l2g, _, mg_, _), (l2o, _, mo, _) in zip(hg, ho):
+        assert rel_err(l2g[None, :], l2o[None, :]) < 1e-9
+        assert abs(mg_ - mo) <= 1e-8 * mo
+    for a, b in zip(sg, so):
+        assert rel_err(a[ng:-ng, ng:-ng, ng:-ng], b[ng:-ng, ng:-ng, ng:-ng]) < 1e-9
