@@ -1985,14 +1985,30 @@ int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
 static int implicit_begin(agx_ctx* c, int write_x);
 int agx_phase_matrix_residual(agx_ctx* c, double* mr);
 namespace {
+// every solver on the plane-major arrays (DPLUR, BDPLUR; LU-SGS / BLU-SGS on the record
+// sweeps); the diagonal-ordered LU-SGS path keeps b, x and the diagonal in its own arrays
+int mg_solver_ok(agx_ctx* c) {
+  if (AGX_NEQ != 5) return fail("multigrid: built for the 5-equation sets");
+  if (!c->sp.implicit) return fail("multigrid: implicit time integration only");
+  for (auto& blk : c->blocks)
+    if (blk.d.d2.base)
+      return fail("multigrid: not on the diagonal-ordered LU-SGS path (scalar DPLUR, BDPLUR, "
+                  "BLU-SGS, or AGX_LUSGS=plane for scalar LU-SGS)");
+  return 0;
+}
+// x of a block's planes changed outside sweeps and exchanges: the records' copy follows
+void mg_x_records(agx_ctx* c, Block& b) {
+  if (b.d.sw_dyn)
+    hipLaunchKernelGGL(k_mg_x_records, dim3((unsigned)((b.d.nplane + 255) / 256)), dim3(256), 0,
+                       c->stream, b.d);
+}
 int mg_check(agx_ctx* f, agx_ctx* cz, int blk) {
   if (!f || !cz) return fail("mg: null context");
   if (blk < 0 || blk >= (int)f->blocks.size() || blk >= (int)cz->blocks.size())
     return fail("mg: bad block %d", blk);
   if (f->device != cz->device) return fail("mg: the two levels live on different devices");
   for (agx_ctx* c : {f, cz})
-    if (!(c->sp.implicit && c->cfg.matrix_solver == AGX_SOLVER_DPLUR) || c->blocks[blk].d.d2.base)
-      return fail("multigrid: built for scalar DPLUR");
+    if (mg_solver_ok(c)) return 1;
   return 0;
 }
 int mg_planes(agx_ctx* c, Block& b, double** p) {     // AGX_NEQ zeroed planes, once
@@ -2093,13 +2109,14 @@ int agx_mg_restrict(agx_ctx* f, agx_ctx* cz, int blk, int what, const int32_t* t
   if (what == AGX_MG_FORCING)
     hipLaunchKernelGGL(k_mg_axmb, cell_grid(bc.d, CELL_BLOCK), CELL_BLOCK, 0, cz->stream, bc.d,
                        cz->gas, cz->sp);
+  if (what == AGX_MG_UPDATE) mg_x_records(cz, bc);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 int agx_mg_matrix_residual(agx_ctx* c, double* mr) {
+  if (mg_solver_ok(c)) return 1;
   for (auto& blk : c->blocks) {
-    if (blk.d.d2.base) return fail("multigrid: built for scalar DPLUR");
     if (mg_planes(c, blk, &blk.mg_mres)) return 1;
     blk.d.mg_mres = blk.mg_mres;
   }
@@ -2111,8 +2128,11 @@ int agx_mg_invert_diagonal(agx_ctx* c) { return implicit_begin(c, 0); }
 // gridLevel::ResetDiagonal (gridLevel.cpp:408-412) of a coarse level, whose residual adds to the
 // diagonal (SolverDev::diag_add); the finest level's kernels overwrite theirs
 int agx_mg_reset_diagonal(agx_ctx* c) {
-  for (auto& blk : c->blocks)
+  for (auto& blk : c->blocks) {
     HIPCHK(hipMemsetAsync(blk.d.a, 0, sizeof(double) * blk.d.nplane, c->stream));
+    if (blk.d.am)
+      HIPCHK(hipMemsetAsync(blk.d.am, 0, sizeof(double) * AGX_NJ * blk.d.nplane, c->stream));
+  }
   return 0;
 }
 
@@ -2145,6 +2165,8 @@ int agx_mg_prolong(agx_ctx* cz, agx_ctx* f, int blk, const int32_t* tc, const do
   if (mg_order(cz, f)) return 1;
   hipLaunchKernelGGL(k_mg_prolong, cell_grid(bf.d, tb), tb, 0, f->stream, bf.d, m,
                      (const double*)bc.mg_nodes, bc.d.ni, bc.d.nj, bc.d.nk);
+  mg_x_records(cz, bc);
+  mg_x_records(f, bf);
   HIPCHK(hipGetLastError());
   return 0;
 }

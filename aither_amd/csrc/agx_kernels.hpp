@@ -268,7 +268,10 @@ k_block_diag_inv(BlockDev b, GasDev g, SolverDev sp) {
     if (AGX_NEQ > 5) dt_ += turb_inv_jac(l, au, true);
   }
 #pragma unroll
-  for (int e = 0; e < AGX_NJ; ++e) b.am[(long)e * b.nplane + q] = D[e];
+  for (int e = 0; e < AGX_NJ; ++e) {
+    double* am = b.am + (long)e * b.nplane + q;
+    *am = sp.diag_add ? *am + D[e] : D[e];       // (a coarse multigrid level, see SolverDev)
+  }
   if (AGX_NEQ > 5) {       // the same number for k and omega (turbModel::InvJac)
     b.am_t[q] = dt_;
     b.am_t[b.nplane + q] = dt_;
@@ -2468,6 +2471,17 @@ __device__ __forceinline__ void rhs_b(const BlockDev& b, const GasDev& g,
   }
 }
 
+// b of the LU-SGS sweeps on a multigrid level: the forcing term is part of it
+// (linearSolver.cpp:377, :422; DPLUR adds it beside b, :503, and A x - b has none, :72-75)
+__device__ __forceinline__ void rhs_bf(const BlockDev& b, const GasDev& g,
+                                       const SolverDev& sp, long q, double* out) {
+  rhs_b(b, g, sp, q, out);
+  if (b.mg_forcing) {
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) out[e] += b.mg_forcing[(long)e * b.nplane + q];
+  }
+}
+
 // procBlock::ImplicitLower / ImplicitUpper procBlock.cpp:1056-1163 with
 // ProjC2CDist :6316-6342; accumulates (L - U) or parts of it.
 __device__ __forceinline__ void add_off_diag(const BlockDev& b, const GasDev& g,
@@ -2671,7 +2685,7 @@ k_implicit_begin(BlockDev b, GasDev g, SolverDev sp, int* err, int write_x) {
   const long q = b.idx(i, j, k);
   if (b.sw_rhs) {       // the right-hand side, cell-major, for the plane-by-plane sweeps
     double rb[AGX_NEQ];
-    rhs_b(b, g, sp, q, rb);
+    rhs_bf(b, g, sp, q, rb);
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) b.sw_rhs[q * SW_RHS + e] = rb[e];
   }
@@ -2792,7 +2806,7 @@ __device__ __forceinline__ void lusgs_plane_cell(const BlockDev& b, const GasDev
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e) rb[e] = b.sw_rhs[q * SW_RHS + e];
     } else {
-      rhs_b(b, g, sp, q, rb);
+      rhs_bf(b, g, sp, q, rb);
     }
   };
   if (FORWARD) {
@@ -3166,12 +3180,35 @@ k_mg_axmb(BlockDev b, GasDev g, SolverDev sp) {
   add_off_diag(b, g, sp, b.x, i, j, k, q, false, -1.0, acc);
   rhs_b(b, g, sp, q, rb);
   load5(b.x, q, xc);
-  const double a = b.a[q];
+  double ax[AGX_NEQ];
+  if (sp.block) {
+    double m[AGX_NJ];
+#pragma unroll
+    for (int e = 0; e < AGX_NJ; ++e) m[e] = b.am[(long)e * b.nplane + q];
+    mat_vec5(m, xc, ax);
+  } else {
+    const double a = b.a[q];
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e) ax[e] = xc[e] * a;
+  }
 #pragma unroll
   for (int e = 0; e < AGX_NEQ; ++e) {
     double* fo = b.mg_forcing + (long)e * b.nplane + q;
-    *fo = (xc[e] * a - acc[e] - rb[e]) + *fo;
+    *fo = (ax[e] - acc[e] - rb[e]) + *fo;
   }
+  if (b.sw_rhs) {       // (the record sweeps read b from their records)
+    rhs_b(b, g, sp, q, rb);
+#pragma unroll
+    for (int e = 0; e < AGX_NEQ; ++e)
+      b.sw_rhs[q * SW_RHS + e] = rb[e] + b.mg_forcing[(long)e * b.nplane + q];
+  }
+}
+// the records' copy of x after something else than a sweep or an exchange wrote the planes
+__global__ void k_mg_x_records(BlockDev b) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.nplane) return;
+#pragma unroll
+  for (int e = 0; e < AGX_NEQ; ++e) b.sw_dyn[t * SW_DYN + SW_X + e] = b.x[e][t];
 }
 // x -= coarseDu, ghost cells included (linearSolver::SubtractFromUpdate :120-126);
 // save: coarseDu = x

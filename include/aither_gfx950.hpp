@@ -184,7 +184,7 @@ class hotPath {
 // but the coarsest and per block, the arrays gridLevel::Coarsen builds: toCoarse_ (int32
 // triples), volWeightFactor_, prolongCoeffs_ (7 doubles), all per physical fine cell in
 // k-j-i order.  The cycle is the reference's; what crosses between two levels runs in the
-// library (agx_mg_*).  Scalar DPLUR.
+// library (agx_mg_*).
 class multigrid {
   struct transfer {
     std::vector<int32_t> toCoarse;

@@ -1104,13 +1104,54 @@ def test_multigrid_synthetic_parity(agx, oracle, cycle, nblocks, levels):
 
 
 @pytest.mark.gpu
-def test_multigrid_is_refused_outside_scalar_dplur(agx):
-    """The multigrid calls are built for scalar DPLUR: a level solved with LU-SGS (the
-    diagonal-ordered sweeps have no forcing term) refuses them by name."""
+@pytest.mark.parametrize("solver,env", [("bdplur", {}), ("blusgs", {}), ("blusgs", {"AGX_SWEEP_PIPE": "0"}),
+                                        ("lusgs", {"AGX_LUSGS": "plane"})])
+def test_multigrid_other_solvers_parity(agx, oracle, solver, env):
+    """The forcing term in the other relaxations that run on the plane-major arrays: BDPLUR
+    (beside b), BLU-SGS on the pipelined and on the launch-per-hyperplane record sweeps and
+    scalar LU-SGS on the hyperplane form (inside b, read from the records) -- W cycle, three
+    levels, two blocks with a connection, viscous (the thin-shear-layer Jacobians on every
+    level), against the oracle."""
+    from aither_amd.solver import MultigridSolver
+    wall = {3: ("viscousWall", 2)}
+    kw = dict(n=(12, 10, 8), nblocks=2, axis="i", stretch=1.1, levels=3, cycle="W", bcs=wall,
+              equation_set="navierStokes", time_integration="implicitEuler",
+              matrix_solver=solver, matrix_sweeps=2, cfl=20.0)
+    cg, tg = synthetic.multigrid_levels(**kw)
+    co, to = synthetic.multigrid_levels(**kw)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        sg = MultigridSolver(agx, cg, tg)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    so = MultigridSolver(oracle, co, to)
+    g = cg[0].ng
+    for nn in range(3):
+        og, oo = sg.step(nn), so.step(nn)
+        assert np.allclose(og["l2"], oo["l2"], rtol=1e-9, atol=1e-12 * oo["l2"].max())
+        assert abs(og["matrix"] - oo["matrix"]) <= 1e-7 * oo["matrix"]
+        for lev in range(3):
+            for gb in range(2):
+                for f in ("state", "update"):
+                    a = sg.download(f, gb, lev)[g:-g, g:-g, g:-g]
+                    b = so.download(f, gb, lev)[g:-g, g:-g, g:-g]
+                    assert rel_err(a, b) < 1e-9, (nn, lev, gb, f)
+    sg.close(), so.close()
+
+
+@pytest.mark.gpu
+def test_multigrid_is_refused_on_the_diagonal_ordered_path(agx):
+    """The diagonal-ordered LU-SGS path keeps b, x and the diagonal in its own arrays and has
+    no forcing term: a level on it refuses the multigrid calls by name."""
     from aither_amd.solver import MultigridSolver
     cases, trs = synthetic.multigrid_levels(n=(12, 10, 8), levels=2, time_integration="implicitEuler",
                                             matrix_solver="lusgs", cfl=10.0)
     s = MultigridSolver(agx, cases, trs)
-    with pytest.raises(RuntimeError, match="scalar DPLUR"):
+    with pytest.raises(RuntimeError, match="diagonal-ordered"):
         s.step(0)
     s.close()
