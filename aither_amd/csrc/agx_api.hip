@@ -162,6 +162,7 @@ struct agx_ctx {
   hipGraphExec_t sweep_graph_all[2][2][2] = {};
   // the pipelined half sweep (k_lusgs_pipe): a workgroup per k-plane of every block
   bool mg_coarse = false;                // a coarse multigrid level (agx_mg_restrict made it one)
+  bool mres_plane_form = false;          // agx_mg_matrix_residual: k_matrix_resid on every block
   bool sweep_pipe = true;                // AGX_SWEEP_PIPE=0: one launch per hyperplane
   PipeJob* pipe_jobs[2] = {nullptr, nullptr};   // device: pipeline order back / forward
   int* pipe_slot0 = nullptr;             // device
@@ -1984,18 +1985,20 @@ int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
 // ---- geometric multigrid (include/aither_gfx950.h) -------------------------------------------
 static int implicit_begin(agx_ctx* c, int write_x);
 int agx_phase_matrix_residual(agx_ctx* c, double* mr);
+static int d2_x_copy(agx_ctx* c, Block& b, int to_d2);
+#if AGX_FAST
+static void d2_prepare(agx_ctx* c, Block& blk, int write_x, int again);
+#endif
 namespace {
-// every solver on the plane-major arrays (DPLUR, BDPLUR; LU-SGS / BLU-SGS on the record
-// sweeps); the diagonal-ordered LU-SGS path keeps b, x and the diagonal in its own arrays
 int mg_solver_ok(agx_ctx* c) {
   if (AGX_NEQ != 5) return fail("multigrid: built for the 5-equation sets");
   if (!c->sp.implicit) return fail("multigrid: implicit time integration only");
-  for (auto& blk : c->blocks)
-    if (blk.d.d2.base)
-      return fail("multigrid: not on the diagonal-ordered LU-SGS path (scalar DPLUR, BDPLUR, "
-                  "BLU-SGS, or AGX_LUSGS=plane for scalar LU-SGS)");
   return 0;
 }
+// On the diagonal-ordered LU-SGS path x lives in the D2 arrays; the multigrid kernels work on
+// the planes: current planes before they read, the D2 arrays (tagged) after they wrote.
+int mg_x_to_planes(agx_ctx* c, Block& b) { return b.d.d2.base ? d2_x_copy(c, b, 0) : 0; }
+int mg_x_from_planes(agx_ctx* c, Block& b) { return b.d.d2.base ? d2_x_copy(c, b, 1) : 0; }
 // x of a block's planes changed outside sweeps and exchanges: the records' copy follows
 void mg_x_records(agx_ctx* c, Block& b) {
   if (b.d.sw_dyn)
@@ -2088,6 +2091,8 @@ int agx_mg_restrict(agx_ctx* f, agx_ctx* cz, int blk, int what, const int32_t* t
   if (flush_consn(f) || flush_consn(cz)) return 1;
   MgMap m;
   if (mg_maps(f, bf, tc, vf, nullptr, bc.d.ni, bc.d.nj, bc.d.nk, &m)) return 1;
+  if (what == AGX_MG_UPDATE && mg_x_to_planes(f, bf)) return 1;
+  if (what == AGX_MG_FORCING && mg_x_to_planes(cz, bc)) return 1;   // (ghosts of the exchange)
   if (mg_order(f, cz)) return 1;
   if (what == AGX_MG_STATE) {
     // (coarse.Zero(): ghost cells included, procBlock.hpp:641)
@@ -2109,7 +2114,14 @@ int agx_mg_restrict(agx_ctx* f, agx_ctx* cz, int blk, int what, const int32_t* t
   if (what == AGX_MG_FORCING)
     hipLaunchKernelGGL(k_mg_axmb, cell_grid(bc.d, CELL_BLOCK), CELL_BLOCK, 0, cz->stream, bc.d,
                        cz->gas, cz->sp);
-  if (what == AGX_MG_UPDATE) mg_x_records(cz, bc);
+  if (what == AGX_MG_UPDATE) {
+    mg_x_records(cz, bc);
+    if (mg_x_from_planes(cz, bc)) return 1;
+  }
+#if AGX_FAST
+  // (b of the diagonal-ordered sweeps: formed again, now with the forcing term)
+  if (what == AGX_MG_FORCING && bc.d.d2.base) d2_prepare(cz, bc, 0, 1);
+#endif
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2119,8 +2131,13 @@ int agx_mg_matrix_residual(agx_ctx* c, double* mr) {
   for (auto& blk : c->blocks) {
     if (mg_planes(c, blk, &blk.mg_mres)) return 1;
     blk.d.mg_mres = blk.mg_mres;
+    if (mg_x_to_planes(c, blk)) return 1;
   }
-  return agx_phase_matrix_residual(c, mr);
+  // (the plane form: the diagonal-ordered reductions form the norm only)
+  c->mres_plane_form = true;
+  const int rc = agx_phase_matrix_residual(c, mr);
+  c->mres_plane_form = false;
+  return rc;
 }
 
 int agx_mg_invert_diagonal(agx_ctx* c) { return implicit_begin(c, 0); }
@@ -2140,6 +2157,7 @@ int agx_mg_save_update(agx_ctx* c) {
   for (auto& blk : c->blocks) {
     if (mg_planes(c, blk, &blk.mg_xsave)) return 1;
     blk.d.mg_xsave = blk.mg_xsave;
+    if (mg_x_to_planes(c, blk)) return 1;
     hipLaunchKernelGGL(k_mg_axpy, dim3((unsigned)((blk.d.nplane + 255) / 256)), dim3(256), 0,
                        c->stream, blk.d, 1);
   }
@@ -2156,6 +2174,7 @@ int agx_mg_prolong(agx_ctx* cz, agx_ctx* f, int blk, const int32_t* tc, const do
   if (mg_maps(f, bf, tc, nullptr, cf, bc.d.ni, bc.d.nj, bc.d.nk, &m)) return 1;
   const long nn = (long)(bc.d.ni + 1) * (bc.d.nj + 1) * (bc.d.nk + 1);
   if (!bc.mg_nodes) HIPCHK(hipMalloc((void**)&bc.mg_nodes, sizeof(double) * AGX_NEQ * nn));
+  if (mg_x_to_planes(cz, bc) || mg_x_to_planes(f, bf)) return 1;
   hipLaunchKernelGGL(k_mg_axpy, dim3((unsigned)((bc.d.nplane + 255) / 256)), dim3(256), 0,
                      cz->stream, bc.d, 0);
   const dim3 tb = CELL_BLOCK;
@@ -2167,6 +2186,7 @@ int agx_mg_prolong(agx_ctx* cz, agx_ctx* f, int blk, const int32_t* tc, const do
                      (const double*)bc.mg_nodes, bc.d.ni, bc.d.nj, bc.d.nk);
   mg_x_records(cz, bc);
   mg_x_records(f, bf);
+  if (mg_x_from_planes(cz, bc) || mg_x_from_planes(f, bf)) return 1;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2323,6 +2343,16 @@ int agx_phase_explicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
 }
 
 static int implicit_begin(agx_ctx* c, int write_x);
+#if AGX_FAST
+// k_lusgs_prepare of one block (write_x: a launch that writes x is a writer launch: it tags
+// the values and advances the epoch)
+static void d2_prepare(agx_ctx* c, Block& blk, int write_x, int again) {
+  const BlockDev& b = blk.d;
+  const dim3 grid((b.d2.Pi + TT - 1) / TT, (b.d2.Pj + TT - 1) / TT, b.nk + 2 * b.ng);
+  hipLaunchKernelGGL(k_lusgs_prepare, grid, dim3(256), 0, c->stream, b, c->gas, c->sp,
+                     write_x, write_x ? (unsigned)(++blk.kp_epoch) & 3u : 0u, again);
+}
+#endif
 int agx_phase_implicit_begin(agx_ctx* c) { return implicit_begin(c, 1); }
 // (write_x = 0: gridLevel::InvertDiagonal alone, for a coarse multigrid level)
 static int implicit_begin(agx_ctx* c, int write_x) {
@@ -2331,18 +2361,12 @@ static int implicit_begin(agx_ctx* c, int write_x) {
   for (auto& blk : c->blocks) {
     const BlockDev& b = blk.d;
 #if AGX_FAST
-    if (b.d2.base && !write_x)
-      return fail("multigrid: built for scalar DPLUR (the diagonal-ordered LU-SGS path has no "
-                  "forcing term)");
     if (b.d2.base) {
-      // diagonal terms, b and x0 straight into the D2 arrays of the sweeps
-      const dim3 grid((b.d2.Pi + TT - 1) / TT, (b.d2.Pj + TT - 1) / TT, b.nk + 2 * b.ng);
+      // diagonal terms, b and x0 straight into the D2 arrays of the sweeps (a coarse
+      // multigrid level, write_x = 0: x is the restricted one)
       bool conn = false;
       for (int q = 0; q < 6; ++q) conn = conn || b.side_conn[q] != 0;
-      const int write_x = (c->sp.requires_init || conn) ? 1 : 0;
-      // (a launch that writes x is a writer launch: it tags the values and advances the epoch)
-      hipLaunchKernelGGL(k_lusgs_prepare, grid, dim3(256), 0, c->stream, b, c->gas, c->sp,
-                         write_x, write_x ? (unsigned)(++blk.kp_epoch) & 3u : 0u);
+      d2_prepare(c, blk, write_x && (c->sp.requires_init || conn) ? 1 : 0, 0);
       continue;
     }
 #endif
@@ -2423,7 +2447,7 @@ int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       const BlockDev& b = c->blocks[n].d;
 #if AGX_FAST
-      if (b.d2.base) {
+      if (b.d2.base && !c->mres_plane_form) {
         // (position chunk, k) pairs dealt to the XCDs band by band, see the kernels
         const long nwg = mresid_wgs(c, b);
         if (c->mresid_march)

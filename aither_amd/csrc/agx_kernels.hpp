@@ -3109,7 +3109,9 @@ k_matrix_resid(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
 #pragma unroll
       for (int e = 5; e < AGX_NEQ; ++e) ax[e] = b.am_t[(long)(e - 5) * b.nplane + q] * xc[e];
     } else {
-      const double a = b.a[q];
+      // (a block on the diagonal-ordered path: the finished diagonal is in the aInv_ plane,
+      // k_lusgs_prepare)
+      const double a = b.d2.base ? b.ainv[q] : b.a[q];
       const double at = AGX_NEQ > 5 ? b.a_t[q] : 0.0;
 #pragma unroll
       for (int e = 0; e < AGX_NEQ; ++e) ax[e] = xc[e] * (e < 5 ? a : at);
@@ -3187,7 +3189,7 @@ k_mg_axmb(BlockDev b, GasDev g, SolverDev sp) {
     for (int e = 0; e < AGX_NJ; ++e) m[e] = b.am[(long)e * b.nplane + q];
     mat_vec5(m, xc, ax);
   } else {
-    const double a = b.a[q];
+    const double a = b.d2.base ? b.ainv[q] : b.a[q];
 #pragma unroll
     for (int e = 0; e < AGX_NEQ; ++e) ax[e] = xc[e] * a;
   }

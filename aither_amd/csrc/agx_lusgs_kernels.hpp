@@ -102,7 +102,9 @@ __global__ void __launch_bounds__(256) k_d2_x_copy(BlockDev b, int to_d2, unsign
 // without connection surfaces no ghost x is ever a neighbour) -- skip 48 B/cell.
 // Grid: (Pi / 32, Pj / 32, Pk) tiles of the padded box, 256 threads.
 __global__ void __launch_bounds__(256)
-k_lusgs_prepare(BlockDev b, GasDev g, SolverDev sp, int write_x, unsigned tag) {
+k_lusgs_prepare(BlockDev b, GasDev g, SolverDev sp, int write_x, unsigned tag, int again) {
+  // (again: a second launch on the same residual -- the forcing term of a multigrid level now
+  // exists -- takes the finished diagonal of the first one)
   __shared__ double sv[6][TT][TRS];
   __shared__ unsigned short s_tab[TT * TT];
   const D2Dev& z = b.d2;
@@ -134,11 +136,18 @@ k_lusgs_prepare(BlockDev b, GasDev g, SolverDev sp, int write_x, unsigned tag) {
       if (phys) {
         double dvt = (b.vol[q] * (1.0 + sp.zeta)) / (b.dt[q] * sp.theta);
         if (sp.dual_time_cfl > 0.0) dvt += fmax(b.specrad[q], 0.0) / sp.dual_time_cfl;
-        // (the plane-major a_ is not written back: on this path nobody reads it again --
-        // 1/a goes to the D2 arrays -- and the next residual assigns it afresh)
-        const double a = b.a[q] * sp.relax + dvt;
+        // (the plane-major a_ itself is not written back on the finest level: the next
+        // residual assigns it afresh.  The finished diagonal goes to the D2 arrays as 1/a
+        // and, for the multigrid calls that work on the planes, into the aInv_ plane,
+        // which nothing else uses on this path.)
+        const double a = again ? b.ainv[q] : b.a[q] * sp.relax + dvt;
+        b.ainv[q] = a;
+        // (a coarse multigrid level: the reference's a_ holds the finished diagonal from
+        // here on, and a second restriction to the level within the iteration adds its
+        // spectral radii to THAT -- SolverDev::diag_add)
+        if (sp.diag_add) b.a[q] = a;
         ainv[m] = 1.0 / a;
-        rhs_b(b, g, sp, q, bb[m]);
+        rhs_bf(b, g, sp, q, bb[m]);
         if (sp.requires_init) {
 #pragma unroll
           for (int e = 0; e < AGX_NEQ; ++e) x0[m][e] = bb[m][e] * ainv[m];

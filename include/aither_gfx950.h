@@ -349,10 +349,9 @@ int agx_nearest_wall_distance(agx_ctx *ctx, int64_t ncell, const double *cell_ce
  * set-up, aither_amd/case/multigrid.py).  These calls move data between block `blk` of a
  * fine context and the same block of the next coarser one, and give a level what
  * mgSolution::CycleAtLevel (mgSolution.cpp:160-205) needs beyond the phases above.  Both
- * contexts live on the same device.  The forcing term is carried by every relaxation that
- * runs on the plane-major arrays -- DPLUR, BDPLUR, BLU-SGS, scalar LU-SGS in its
- * hyperplane form (AGX_LUSGS=plane) --; a level on the diagonal-ordered LU-SGS path, which
- * keeps b, x and the diagonal in its own arrays, refuses these calls (5-equation library).  `to_coarse` [nk][nj][ni][3] (int32, host):
+ * contexts live on the same device.  The forcing term is carried by all four relaxations of
+ * the 5-equation library (DPLUR, BDPLUR, BLU-SGS, scalar LU-SGS on its diagonal-ordered
+ * production path and in its hyperplane form); the 7-equation library refuses these calls.  `to_coarse` [nk][nj][ni][3] (int32, host):
  * the coarse cell (i, j, k) of every physical cell of the fine block. */
 enum { AGX_MG_STATE = 0, AGX_MG_UPDATE = 1, AGX_MG_FORCING = 2 };
 /* BlockRestriction (procBlock.hpp:636-690) of

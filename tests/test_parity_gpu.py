@@ -1105,13 +1105,15 @@ def test_multigrid_synthetic_parity(agx, oracle, cycle, nblocks, levels):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("solver,env", [("bdplur", {}), ("blusgs", {}), ("blusgs", {"AGX_SWEEP_PIPE": "0"}),
-                                        ("lusgs", {"AGX_LUSGS": "plane"})])
+                                        ("lusgs", {"AGX_LUSGS": "plane"}), ("lusgs", {})])
 def test_multigrid_other_solvers_parity(agx, oracle, solver, env):
-    """The forcing term in the other relaxations that run on the plane-major arrays: BDPLUR
-    (beside b), BLU-SGS on the pipelined and on the launch-per-hyperplane record sweeps and
-    scalar LU-SGS on the hyperplane form (inside b, read from the records) -- W cycle, three
-    levels, two blocks with a connection, viscous (the thin-shear-layer Jacobians on every
-    level), against the oracle."""
+    """The forcing term in the other relaxations: BDPLUR (beside b), BLU-SGS on the pipelined
+    and on the launch-per-hyperplane record sweeps, scalar LU-SGS on the hyperplane form
+    (inside b, read from the records) and on the production path -- the diagonal-ordered
+    pipelined sweeps, where b with the forcing term is formed by k_lusgs_prepare, x crosses
+    between the D2 arrays and the planes around every transfer and the matrix residual is
+    formed on the planes -- W cycle, three levels, two blocks with a connection, viscous,
+    against the oracle."""
     from aither_amd.solver import MultigridSolver
     wall = {3: ("viscousWall", 2)}
     kw = dict(n=(12, 10, 8), nblocks=2, axis="i", stretch=1.1, levels=3, cycle="W", bcs=wall,
@@ -1145,13 +1147,15 @@ def test_multigrid_other_solvers_parity(agx, oracle, solver, env):
 
 
 @pytest.mark.gpu
-def test_multigrid_is_refused_on_the_diagonal_ordered_path(agx):
-    """The diagonal-ordered LU-SGS path keeps b, x and the diagonal in its own arrays and has
-    no forcing term: a level on it refuses the multigrid calls by name."""
+def test_multigrid_is_refused_by_the_seven_equation_library(agx_rans):
+    """The multigrid calls are built for the 5-equation sets: the rans library refuses them
+    by name."""
     from aither_amd.solver import MultigridSolver
-    cases, trs = synthetic.multigrid_levels(n=(12, 10, 8), levels=2, time_integration="implicitEuler",
-                                            matrix_solver="lusgs", cfl=10.0)
-    s = MultigridSolver(agx, cases, trs)
-    with pytest.raises(RuntimeError, match="diagonal-ordered"):
+    cases, trs = synthetic.multigrid_levels(n=(12, 10, 8), levels=2, bcs=RANS_WALL,
+                                            equation_set="rans", turbulence_model="sst2003",
+                                            time_integration="implicitEuler",
+                                            matrix_solver="dplur", matrix_sweeps=2, cfl=10.0)
+    s = MultigridSolver(agx_rans, cases, trs)
+    with pytest.raises(RuntimeError, match="5-equation"):
         s.step(0)
     s.close()
