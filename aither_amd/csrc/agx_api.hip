@@ -44,6 +44,7 @@ struct Block {
   double* blockmat = nullptr; // block-matrix solvers: a_ | aInv_ | velocityGrad_ planes
   double* sweep_rec = nullptr; // plane-by-plane sweeps: geo | dyn | rhs records (k_sweep_records)
   bool sweep_geo_built = false; // the (static) geometry records exist
+  bool x_planes_current = false; // D2 path: the planes of x equal the D2 arrays (multigrid calls)
   // multigrid: forcing | matrix residual | saved update planes (each allocated on first
   // use); the transfer maps of this block as the FINE side (device copies, keyed by the
   // host pointers they were uploaded from); node values of this block as the coarse side
@@ -408,6 +409,10 @@ int ensure_halo_buf(agx_ctx* c, long ndoubles) {
 // what a halo exchange moves: the state planes, or x -- which the D2 LU-SGS path
 // keeps in its own arrays and index space (maps dst2 / src2)
 bool halo_in_d2(const Block& b, int what) { return what == AGX_HALO_UPDATE && b.d.d2.base; }
+// something is about to write x where it lives (the D2 arrays on the diagonal-ordered path)
+void x_changed(agx_ctx* c) {
+  for (auto& blk : c->blocks) blk.x_planes_current = false;
+}
 Planes5 halo_planes(Block& b, int what) {
   Planes5 r;
   // (the scatter of an exchange of x also refreshes the sweep records' copy)
@@ -1777,6 +1782,7 @@ static int field_info(Block& b, int field, double* const** p, int* ncomp, int* g
 // x of the D2 LU-SGS path <-> the SoA planes the field transfers use
 static int d2_x_copy(agx_ctx* c, Block& b, int to_d2) {
 #if AGX_FAST
+  b.x_planes_current = true;
   const long n = (long)b.d.d2.Pi * b.d.d2.Pj * (b.d.nk + 2 * b.d.ng);
   hipLaunchKernelGGL(k_d2_x_copy, dim3((n + 255) / 256), dim3(256), 0, c->stream, b.d, to_d2,
                      to_d2 ? (unsigned)(++b.kp_epoch) & 3u : 0u);
@@ -1969,6 +1975,7 @@ int agx_nearest_wall_distance(agx_ctx* c, int64_t ncell, const double* cen, int6
 }
 
 int agx_field_upload(agx_ctx* c, int id, int field, const double* in) {
+  x_changed(c);
   c->ghosts_prefilled = false;
   c->state_is_time_n = false;
   if (flush_consn(c)) return 1;
@@ -1997,7 +2004,11 @@ int mg_solver_ok(agx_ctx* c) {
 }
 // On the diagonal-ordered LU-SGS path x lives in the D2 arrays; the multigrid kernels work on
 // the planes: current planes before they read, the D2 arrays (tagged) after they wrote.
-int mg_x_to_planes(agx_ctx* c, Block& b) { return b.d.d2.base ? d2_x_copy(c, b, 0) : 0; }
+// (x_planes_current: nothing wrote the D2 x since the last copy -- sweeps, exchanges, the
+// prepare kernel and uploads clear it, x_changed)
+int mg_x_to_planes(agx_ctx* c, Block& b) {
+  return b.d.d2.base && !b.x_planes_current ? d2_x_copy(c, b, 0) : 0;
+}
 int mg_x_from_planes(agx_ctx* c, Block& b) { return b.d.d2.base ? d2_x_copy(c, b, 1) : 0; }
 // x of a block's planes changed outside sweeps and exchanges: the records' copy follows
 void mg_x_records(agx_ctx* c, Block& b) {
@@ -2356,6 +2367,7 @@ static void d2_prepare(agx_ctx* c, Block& blk, int write_x, int again) {
 int agx_phase_implicit_begin(agx_ctx* c) { return implicit_begin(c, 1); }
 // (write_x = 0: gridLevel::InvertDiagonal alone, for a coarse multigrid level)
 static int implicit_begin(agx_ctx* c, int write_x) {
+  x_changed(c);
   Timer t(c, G_PREPARE);
   c->sp.un_is_u = c->state_is_time_n ? 1 : 0;   // (read by every rhs_b of this iteration)
   for (auto& blk : c->blocks) {
@@ -2386,6 +2398,7 @@ static int implicit_begin(agx_ctx* c, int write_x) {
 }
 
 int agx_phase_relax_forward(agx_ctx* c, int sweep) {
+  x_changed(c);
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
   bool swept = false;
@@ -2413,6 +2426,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
 }
 
 int agx_phase_relax_backward(agx_ctx* c, int sweep) {
+  x_changed(c);
   if (!is_lusgs_solver(c)) return 0;
   Timer t(c, G_SWEEP);
   const int full = sweep > 0 || c->sp.requires_init;
@@ -2485,6 +2499,7 @@ int agx_phase_implicit_update(agx_ctx* c, int mm, double* l2, agx_linf* linf) {
 
 // ---- halo -----------------------------------------------------------------
 int agx_halo_swap_local(agx_ctx* c, int what) {
+  if (what == AGX_HALO_UPDATE) x_changed(c);
   if (c->conns.empty()) return 0;
   Timer t(c, G_BC);
   if (c->halo_batch && c->halo_batch_sides > 0) {
@@ -2551,6 +2566,7 @@ int agx_halo_pack(agx_ctx* c, int id, int what, double* dev_buf) {
   return 0;
 }
 int agx_halo_unpack(agx_ctx* c, int id, int what, const double* dev_buf) {
+  if (what == AGX_HALO_UPDATE) x_changed(c);
   c->ghosts_prefilled = false;
   if (id < 0 || id >= (int)c->conns.size()) return fail("bad connection id");
   Conn& k = c->conns[id];
