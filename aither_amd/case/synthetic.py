@@ -152,13 +152,13 @@ def stacked_blocks_case(n=(16, 16, 16), nblocks=2, axis="k", stretch=1.0,
 
 
 def multigrid_levels(n=(16, 16, 16), nblocks=1, axis="k", levels=2, cycle="V", stretch=1.0,
-                     bcs=None, amplitude=0.05, **deck_kw):
+                     bcs=None, amplitude=0.05, ranks=None, **deck_kw):
     """(cases, transfers) of aither_amd.case.multigrid.build_levels for nblocks boxes stacked
     along `axis` (one box: no connections); the finest level's state is perturbed."""
     from . import multigrid as _mg
     deck, coords = _stacked(n, nblocks, axis, stretch, bcs, deck_kw)
     deck.multigrid_cycle = cycle
-    cases, transfers = _mg.build_levels(deck, coords, levels, _b.build_case)
+    cases, transfers = _mg.build_levels(deck, coords, levels, _b.build_case, ranks=ranks)
     if amplitude:
         perturbed_state(cases[0], amplitude)
     return cases, transfers

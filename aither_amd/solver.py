@@ -367,9 +367,14 @@ class MultigridSolver:
     (V: 1 coarse visit, W: 2) is host logic over the library's phases and the agx_mg_* calls;
     the same driver runs the product library and the test oracle."""
 
-    def __init__(self, api, cases, transfers, device=0, stream=None):
+    def __init__(self, api, cases, transfers, device=0, stream=None, rank=0, exchange=None):
+        """rank / exchange: one rank of a multi-process run -- the blocks of every level live
+        on the rank of their finest ancestor; exchange() returns a fresh DistExchange-like
+        object per level (the levels' connections to other ranks go through the library's
+        exchange table, agx_halo_exchange).  The norms a rank gets back are its own."""
         self.api = api
-        self.levels = [Solver(api, c, device=device, stream=stream) for c in cases]
+        self.levels = [Solver(api, c, device=device, rank=rank, stream=stream,
+                              exchange=exchange() if exchange else None) for c in cases]
         self.transfers = []
         for trs in transfers:
             keep = []
@@ -403,7 +408,7 @@ class MultigridSolver:
     def _boundary_and_residual(self, s, mm, cfl):
         api = self.api
         api.check(api.phase_bc_faces(s.ctx), "phase_bc_faces")
-        api.check(api.halo_swap_local(s.ctx, abi.HALO_STATE), "halo_swap_local")
+        api.check(api.halo_exchange(s.ctx, abi.HALO_STATE), "halo_exchange")
         api.check(api.phase_bc_edges(s.ctx), "phase_bc_edges")
         api.check(api.phase_residual(s.ctx, mm, cfl), "phase_residual")
 
@@ -412,12 +417,12 @@ class MultigridSolver:
         api, s = self.api, self.levels[lev]
         lusgs = s.cfg.matrix_solver in (abi.SOLVER["lusgs"], abi.SOLVER["blusgs"])
         for ii in range(sweeps):
-            api.check(api.halo_swap_local(s.ctx, abi.HALO_UPDATE), "halo_swap_local")
+            api.check(api.halo_exchange(s.ctx, abi.HALO_UPDATE), "halo_exchange")
             api.check(api.phase_relax_forward(s.ctx, ii), "relax_forward")
             if lusgs:
-                api.check(api.halo_swap_local(s.ctx, abi.HALO_UPDATE), "halo_swap_local")
+                api.check(api.halo_exchange(s.ctx, abi.HALO_UPDATE), "halo_exchange")
                 api.check(api.phase_relax_backward(s.ctx, ii), "relax_backward")
-        api.check(api.halo_swap_local(s.ctx, abi.HALO_UPDATE), "halo_swap_local")
+        api.check(api.halo_exchange(s.ctx, abi.HALO_UPDATE), "halo_exchange")
         mres = C.c_double(0.0)
         api.check(api.mg_matrix_residual(s.ctx, C.byref(mres)), "mg_matrix_residual")
         return mres.value
@@ -438,7 +443,7 @@ class MultigridSolver:
             t = trs[gb]
             api.check(api.mg_restrict(f.ctx, c.ctx, bid, 1, self._p(t["tc"], C.c_int32),
                                       self._p(t["vf"], C.c_double)), "mg_restrict update")
-        api.check(api.halo_swap_local(c.ctx, abi.HALO_UPDATE), "halo_swap_local")
+        api.check(api.halo_exchange(c.ctx, abi.HALO_UPDATE), "halo_exchange")
         for gb, bid in f.block_ids.items():
             t = trs[gb]
             api.check(api.mg_restrict(f.ctx, c.ctx, bid, 2, self._p(t["tc"], C.c_int32),

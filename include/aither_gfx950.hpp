@@ -184,7 +184,10 @@ class hotPath {
 // but the coarsest and per block, the arrays gridLevel::Coarsen builds: toCoarse_ (int32
 // triples), volWeightFactor_, prolongCoeffs_ (7 doubles), all per physical fine cell in
 // k-j-i order.  The cycle is the reference's; what crosses between two levels runs in the
-// library (agx_mg_*).
+// library (agx_mg_*).  Runs of more than one rank: every level's hotPath gets the rank's
+// blocks of that level and its own SetExchange / UseRccl; the levels' connections to other
+// ranks then go through agx_halo_exchange like the finest one's (restriction and prolongation
+// never leave a block), and the norms Iterate returns are this rank's.
 class multigrid {
   struct transfer {
     std::vector<int32_t> toCoarse;
@@ -202,7 +205,7 @@ class multigrid {
   // gridLevel::GetBoundaryConditions, CalcResidual, CalcTimeStep
   void BoundaryAndResidual(int ll, int mm, double cfl) {
     Check(AGX_SYM(phase_bc_faces)(Ctx(ll)), "multigrid (phase_bc_faces)");
-    Check(AGX_SYM(halo_swap_local)(Ctx(ll), AGX_HALO_STATE), "multigrid (halo_swap_local)");
+    Check(AGX_SYM(halo_exchange)(Ctx(ll), AGX_HALO_STATE), "multigrid (halo_exchange)");
     Check(AGX_SYM(phase_bc_edges)(Ctx(ll)), "multigrid (phase_bc_edges)");
     Check(AGX_SYM(phase_residual)(Ctx(ll), mm, cfl), "multigrid (phase_residual)");
   }
@@ -231,14 +234,14 @@ class multigrid {
   // linearSolver::Relax (linearSolver.cpp:430-470, :509-536); returns sum(r^2) / size
   double Relax(int ll, int sweeps) {
     for (int ii = 0; ii < sweeps; ++ii) {
-      Check(AGX_SYM(halo_swap_local)(Ctx(ll), AGX_HALO_UPDATE), "multigrid::Relax (SwapUpdate)");
+      Check(AGX_SYM(halo_exchange)(Ctx(ll), AGX_HALO_UPDATE), "multigrid::Relax (SwapUpdate)");
       Check(AGX_SYM(phase_relax_forward)(Ctx(ll), ii), "multigrid::Relax");
       if (lusgs_) {
-        Check(AGX_SYM(halo_swap_local)(Ctx(ll), AGX_HALO_UPDATE), "multigrid::Relax (SwapUpdate)");
+        Check(AGX_SYM(halo_exchange)(Ctx(ll), AGX_HALO_UPDATE), "multigrid::Relax (SwapUpdate)");
         Check(AGX_SYM(phase_relax_backward)(Ctx(ll), ii), "multigrid::Relax");
       }
     }
-    Check(AGX_SYM(halo_swap_local)(Ctx(ll), AGX_HALO_UPDATE), "multigrid::Relax (SwapUpdate)");
+    Check(AGX_SYM(halo_exchange)(Ctx(ll), AGX_HALO_UPDATE), "multigrid::Relax (SwapUpdate)");
     double l2 = 0.0;
     Check(AGX_SYM(mg_matrix_residual)(Ctx(ll), &l2), "multigrid::Relax (Residual)");
     return l2;
@@ -259,7 +262,7 @@ class multigrid {
       Check(AGX_SYM(mg_restrict)(Ctx(fi), Ctx(ci), static_cast<int>(bb), AGX_MG_UPDATE,
                                  tr[bb].toCoarse.data(), tr[bb].volFac.data()),
             "multigrid::Restriction (update)");
-    Check(AGX_SYM(halo_swap_local)(Ctx(ci), AGX_HALO_UPDATE), "multigrid::Restriction (SwapUpdate)");
+    Check(AGX_SYM(halo_exchange)(Ctx(ci), AGX_HALO_UPDATE), "multigrid::Restriction (SwapUpdate)");
     for (size_t bb = 0; bb < tr.size(); ++bb)
       Check(AGX_SYM(mg_restrict)(Ctx(fi), Ctx(ci), static_cast<int>(bb), AGX_MG_FORCING,
                                  tr[bb].toCoarse.data(), nullptr),

@@ -17,7 +17,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT, _oracle_lib
 from aither_amd import abi
 from aither_amd.case import synthetic
-from aither_amd.solver import Solver, PhasedSolver, DistExchange
+from aither_amd.solver import Solver, PhasedSolver, DistExchange, MultigridSolver
 
 FARFIELD = {s: ("characteristic", 1) for s in range(1, 7)}
 KW = {
@@ -272,4 +272,72 @@ def test_walllaw_two_ranks_match_single_process(oracle, in_library):
     for r in range(2):
         assert np.array_equal(core(res[r][0]), core(ref.download("state", r)))
         assert np.array_equal(res[r][1], ref.download("residual", r))
+    ref.close()
+
+
+MG_KW = {
+    "dplur": dict(bcs=FARFIELD, inviscid_flux="ausm", limiter="none",
+                  time_integration="implicitEuler", matrix_solver="dplur",
+                  matrix_sweeps=4, cfl=20.0),
+    "blusgs": dict(bcs=FARFIELD, time_integration="implicitEuler", matrix_solver="blusgs",
+                   matrix_sweeps=2, cfl=10.0),
+}
+
+
+def _mg_levels(world, kind, cycle, ranks):
+    return synthetic.multigrid_levels((8, 6, 8), nblocks=world, axis="k", levels=3,
+                                      cycle=cycle, stretch=1.1, ranks=ranks, **MG_KW[kind])
+
+
+def _mg_worker(rank, world, port, kind, cycle, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ora = abi.Api(ctypes.CDLL(_oracle_lib()), "ora_")
+    cases, transfers = _mg_levels(world, kind, cycle, list(range(world)))
+    sol = MultigridSolver(ora, cases, transfers, rank=rank,
+                          exchange=lambda: DistExchange(world))
+    for nn in range(steps):
+        sol.step(nn)
+    (gb,) = sol.levels[0].block_ids
+    q.put((rank, sol.download("state", gb), sol.download("update", gb, 1),
+           np.array([h["l2"] ** 2 for h in sol.history])))
+    dist.barrier()
+    sol.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,cycle", [("dplur", "W"), ("blusgs", "V")])
+def test_multigrid_across_ranks_matches_single_process(oracle, kind, cycle):
+    """Every grid level split over the ranks like the finest one (the reference decomposes
+    the finest level and coarsens each rank's blocks, gridLevel.cpp:440-535): the connections
+    of the coarse levels cross the ranks through the same exchange table; restriction and
+    prolongation stay inside a block."""
+    world, steps = 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mg_worker, args=(r, world, port, kind, cycle, steps, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, st, up, l2 = q.get(timeout=300)
+        res[rank] = (st, up, l2)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cases, transfers = _mg_levels(world, kind, cycle, None)
+    ref = MultigridSolver(oracle, cases, transfers)
+    for nn in range(steps):
+        ref.step(nn)
+    ng = cases[0].ng
+    core = lambda a: a[ng:-ng, ng:-ng, ng:-ng]
+    l2sum = sum(res[r][2] for r in range(world))
+    l2ref = np.array([h["l2"] ** 2 for h in ref.history])
+    assert np.allclose(l2sum, l2ref, rtol=1e-12)
+    for r in range(world):
+        assert np.array_equal(core(res[r][0]), core(ref.download("state", r)))
+        assert np.array_equal(core(res[r][1]), core(ref.download("update", r, 1)))
     ref.close()
