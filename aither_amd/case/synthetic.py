@@ -47,7 +47,7 @@ def perturbed_state(case, amplitude=0.05):
 
 def make_deck(**kw):
     d = InputDeck()
-    d.rho_ref, d.t_ref, d.l_ref = 1.225, 288.15, 1.0
+    d.rho_ref, d.t_ref, d.l_ref = 1.225, 288.15, kw.get("l_ref", 1.0)
     d.equation_set = kw.get("equation_set", "euler")
     d.time_integration = kw.get("time_integration", "rk4")
     if d.time_integration == "bdf2":

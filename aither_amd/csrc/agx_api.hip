@@ -2298,15 +2298,17 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
                            cfl, fourth, rec);
       }
 #else
-      if (!AGX_FAST || c->visc_gather || c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH) {
-        // (centralFourth reaches two cells to either side of a face: served by the
-        // one-thread-per-cell form, whose stencil comes straight from the planes)
+    {
+      const bool fourth = c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH;
+      const bool wide_plane = (double)blk.d.nplane * 8.0 >= 4294967296.0;
+      if (!AGX_FAST || c->visc_gather || (fourth && (c->visc_march || wide_plane))) {
+        // (one thread per cell, the stencil straight from the planes: AGX_VISC=gather, and
+        // centralFourth where the tile kernel's 32-bit plane offsets do not reach)
         hipLaunchKernelGGL(k_visc_residual, cell_grid(blk.d, CELL_BLOCK), CELL_BLOCK,
-                           0, c->stream, blk.d, c->gas, c->sp, cfl,
-                           c->cfg.viscous_recon == AGX_VISC_RECON_CENTRAL_4TH ? 1 : 0);
+                           0, c->stream, blk.d, c->gas, c->sp, cfl, fourth ? 1 : 0);
       } else {
         const BlockDev& vb = blk.d;
-        if (c->visc_march || (double)vb.nplane * 8.0 >= 4294967296.0) {
+        if (c->visc_march || wide_plane) {
           const int gx = (vb.ni + VTI - 1) / VTI, gy = (vb.nj + VTJ - 1) / VTJ;
           int nz = std::max(1, std::min(vb.nk / 8, (int)std::lround(2048.0 / (gx * gy))));
           const int kchunk = (vb.nk + nz - 1) / nz;
@@ -2316,16 +2318,22 @@ int agx_phase_residual(agx_ctx* c, int mm, double cfl) {
           continue;
         }
 #if AGX_FAST
-        // 62 x 6 owned cells per workgroup and k-step; persistent workgroups, one per CU
-        // (the kernel's LDS windows fill a CU), each marching an equal share of the
-        // (column tile, k) steps
-        const int gx = (vb.ni + VT_OI - 1) / VT_OI, gy = (vb.nj + VT_OJ - 1) / VT_OJ;
+        // 62 x 6 owned cells per workgroup and k-step (centralFourth: 60 x 6); persistent
+        // workgroups, one per CU (the kernel's LDS windows fill a CU), each marching an equal
+        // share of the (column tile, k) steps
+        const int oi = fourth ? VT_L - 4 : VT_OI;
+        const int gx = (vb.ni + oi - 1) / oi, gy = (vb.nj + VT_OJ - 1) / VT_OJ;
         const long steps = (long)gx * gy * vb.nk;
         const int nwg = (int)std::min<long>(c->num_cu, std::max<long>(1, steps / 8));
-        hipLaunchKernelGGL(k_visc_tile, dim3(nwg), dim3(VT_L, VT_R), 0, c->stream,
-                           make_slab(vb), c->gas, c->sp, cfl, gx, gy);
+        if (fourth)
+          hipLaunchKernelGGL(k_visc_tile<true>, dim3(nwg), dim3(VT_L, VT_R), 0, c->stream,
+                             make_slab(vb), c->gas, c->sp, cfl, gx, gy);
+        else
+          hipLaunchKernelGGL(k_visc_tile<false>, dim3(nwg), dim3(VT_L, VT_R), 0, c->stream,
+                             make_slab(vb), c->gas, c->sp, cfl, gx, gy);
 #endif
       }
+    }
 #endif  // AGX_NEQ == 7
 #if AGX_NEQ != 7     // (the rans viscous kernel accumulates its Jacobians itself)
     if (c->sp.implicit && c->sp.block)

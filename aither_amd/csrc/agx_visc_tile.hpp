@@ -82,13 +82,22 @@ __device__ __forceinline__ void vt_edge(VShared sh, double (*grad)[4], const dou
 // area vectors of the same-direction faces below / above (registers or LDS);
 // per transverse direction the upper / lower edge.  Operands are fetched from the
 // LDS window just in time: held all at once they do not fit the register file.
+// F4 (viscousReconstruction centralFourth, FaceReconCentral4th reconstruction.hpp:335-379):
+// the face state and viscosity come from the four cells around the face instead of two;
+// `wide` hands over the two outer ones -- (u, v, w, T, rho, mu) each and their widths -- once
+// the gradient is complete (they would not fit beside its operands).
+struct VtNoWide {
+  __device__ __forceinline__ void operator()(double*, double*, double&, double&) const {}
+};
+template <bool F4, class Wide>
 __device__ __forceinline__ void vt_face(VShared sh, const GasDev& g, const VRef& rL,
                                         const VRef& rU, const VRef& rhoL, const VRef& rhoU,
                                         double rhoU_reg, double muU_reg, bool u_in_reg,
                                         const double* uReg, const double* aF, const double* aFm,
                                         const double* aFp, const VtEdge& t1u, const VtEdge& t1l,
                                         const VtEdge& t2u, const VtEdge& t2l, double volL,
-                                        double volU, double wL, double wU, double* f) {
+                                        double volU, double wL, double wU, double* f,
+                                        const Wide& wide) {
   double grad[3][4];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -121,20 +130,45 @@ __device__ __forceinline__ void vt_face(VShared sh, const GasDev& g, const VRef&
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) grad[r][c] *= inv_vol;
-  // FaceReconCentral reconstruction.hpp:315-328: the reference forms
-  // coeffs[0] * varD + coeffs[1] * varU with coeffs = {wD, wU} / (wU + wD)
-  // (wU: the cell below the face, wD: the cell above)
-  const double iw = fast_rcp(wL + wU);
-  const double cD = wU * iw, cU = wL * iw;
-  const double vf[3] = {cD * vU[0] + cU * vL[0], cD * vU[1] + cU * vL[1], cD * vU[2] + cU * vL[2]};
-  // T of the face-averaged state: p_f / (rho_f R) with p = rho R T
   const double rL_ = sh[rhoL.row][rhoL.lane][rhoL.var];
   const double mL_ = sh[rhoL.row][rhoL.lane][rhoL.var + 1];          // VS_MU = VS_RHO + 1
   const double rU_ = u_in_reg ? rhoU_reg : sh[rhoU.row][rhoU.lane][rhoU.var];
   const double mU_ = u_in_reg ? muU_reg : sh[rhoU.row][rhoU.lane][rhoU.var + 1];
-  const double rf = cD * rU_ + cU * rL_;
-  const double tf = (cD * rU_ * vU[3] + cU * rL_ * vL[3]) * fast_rcp(rf);
-  const double mu = g.scaling * (cD * mU_ + cU * mL_);
+  double vf[3], tf, mu;
+  if constexpr (F4) {
+    // Newton form on the divided differences of the four cell values (visc_face_state,
+    // agx_kernels.hpp); the reference reconstructs (rho, u, v, w, p) and mu
+    double c0[6], c3[6], w0 = 1.0, w3 = 1.0;
+    wide(c0, c3, w0, w3);
+    const double w1 = wL, w2 = wU;
+    const double r01 = fast_rcp(w0 + w1), r12 = fast_rcp(w1 + w2), r23 = fast_rcp(w2 + w3);
+    const double t012 = fast_rcp(w0 + w1 + w2), t123 = fast_rcp(w1 + w2 + w3);
+    const double q4 = fast_rcp((w0 + w1) + (w2 + w3));
+    const double k3 = w1 * w2, k4 = k3 * (w0 + w1);
+    auto c4 = [&](double u0, double u1, double u2, double u3) {
+      const double g01 = (u1 - u0) * r01, g12 = (u2 - u1) * r12, g23 = (u3 - u2) * r23;
+      const double d3a = (g12 - g01) * t012, d3b = (g23 - g12) * t123;
+      return u1 + w1 * g12 - k3 * d3a - k4 * ((d3b - d3a) * q4);
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vf[c] = c4(c0[c], vL[c], vU[c], c3[c]);
+    const double rf = c4(c0[4], rL_, rU_, c3[4]);
+    const double pf = c4(c0[4] * c0[3], rL_ * vL[3], rU_ * vU[3], c3[4] * c3[3]);   // p / R
+    tf = pf * fast_rcp(rf);
+    mu = g.scaling * c4(c0[5], mL_, mU_, c3[5]);
+  } else {
+    // FaceReconCentral reconstruction.hpp:315-328: the reference forms
+    // coeffs[0] * varD + coeffs[1] * varU with coeffs = {wD, wU} / (wU + wD)
+    // (wU: the cell below the face, wD: the cell above)
+    const double iw = fast_rcp(wL + wU);
+    const double cD = wU * iw, cU = wL * iw;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vf[c] = cD * vU[c] + cU * vL[c];
+    // T of the face-averaged state: p_f / (rho_f R) with p = rho R T
+    const double rf = cD * rU_ + cU * rL_;
+    tf = (cD * rU_ * vU[3] + cU * rL_ * vL[3]) * fast_rcp(rf);
+    mu = g.scaling * (cD * mU_ + cU * mL_);
+  }
   const double lambda = -(2.0 / 3.0) * mu;
   const double trace = grad[0][0] + grad[1][1] + grad[2][2];
   // tau . A  (viscousFlux.cpp:58-135 with the area vector instead of n |A|)
@@ -159,9 +193,18 @@ __device__ __forceinline__ void vt_face(VShared sh, const GasDev& g, const VRef&
 // with a grid of (tiles x k-chunks) workgroups at one workgroup per CU the last round ran
 // a fifth full.  Workgroup n runs on XCD n % 8: ranges are dealt so that each XCD's L2
 // sees neighbouring columns.
+//
+// F4 (centralFourth): a face's state reaches two cells to either side.  Along i the window
+// simply owns two lanes less (lanes 2 .. 61; 0, 1 and 63 only supply data); along j rows 1 and 7
+// -- one wave each -- fetch the cell beyond the window (row -1 / row 8) into registers with the
+// plane they prefetch; along k the own column's plane kk+2 is requested one step earlier and
+// rho, mu and the k-width of plane kk-1 stay in registers.
+template <bool F4>
 __global__ void __launch_bounds__(VT_L * VT_R)
 k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
   __shared__ double sh[VT_R][VT_L][VS_COUNT];
+  constexpr int LO = F4 ? 2 : 1;                        // first owning lane
+  constexpr int OI = F4 ? VT_L - 4 : VT_OI;             // owned cells along i
   const int l = threadIdx.x, ty = threadIdx.y;
   const long S = (long)gx * gy * b.nk;
   const int P = gridDim.x;
@@ -174,13 +217,15 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
   const int k0 = (int)(s_pos - (long)col * b.nk);
   const int k1 = (int)min((long)b.nk, k0 + (s_end - s_pos));
   s_pos += k1 - k0;
-  const int ci = (col % gx) * VT_OI - 1 + l, cj = (col / gx) * VT_OJ - 1 + ty;
-  const bool inner = l >= 1 && l <= VT_OI && ty >= 1 && ty <= VT_OJ;
+  const int ci = (col % gx) * OI - LO + l, cj = (col / gx) * VT_OJ - 1 + ty;
+  const bool inner = l >= LO && l < LO + OI && ty >= 1 && ty <= VT_OJ;
   const bool own = inner && ci < b.ni && cj < b.nj;
   // lower i-face: own cell or the owned cell to the left; lower j-face likewise
-  const bool do_i = l >= 1 && ty >= 1 && ty <= VT_OJ && ci <= b.ni && cj < b.nj;
-  const bool do_j = ty >= 1 && l >= 1 && l <= VT_OI && cj <= b.nj && ci < b.ni;
-  const int ic = min(ci, b.ni), jc = min(cj, b.nj);      // overhanging threads stay in bounds
+  const bool do_i = l >= LO && l <= LO + OI && ty >= 1 && ty <= VT_OJ && ci <= b.ni && cj < b.nj;
+  const bool do_j = ty >= 1 && l >= LO && l < LO + OI && cj <= b.nj && ci < b.ni;
+  // overhanging threads stay in bounds (F4: the lane / row after the face at ni / nj
+  // supplies cell ni+1 / nj+1)
+  const int ic = min(ci, F4 ? b.ni + 1 : b.ni), jc = min(cj, F4 ? b.nj + 1 : b.nj);
   // one 32-bit byte offset per lane (column base, k = 0) + wave-uniform plane
   // offsets; every array is "slab plane base (SGPRs) + offset" (SlabDev::ldb).
   // Unsigned wrap-around makes the k = -1 plane come out right.
@@ -220,14 +265,29 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
   // one plane early: the first pass only forms the k-face below the chunk ----
   int kk = k0 - 1;
   double R1, MU1, V1, WK0, WK1, AK2[3], AIp[3] = {0, 0, 0}, AJp[3] = {0, 0, 0};
+  // F4 only: plane kk+2 of the own column, rho / mu / k-width of plane kk-1, and the cell
+  // beyond the window's rows (u, v, w, T, rho, mu, j-width; rows 1 and 7)
+  double S2[4] = {0, 0, 0, 0}, R2 = 0, MU2 = 0, WK2 = 0, RM = 0, MUM = 0, WKM = 0;
+  double EJ[7] = {0, 0, 0, 0, 0, 0, 0};
+  const bool ej_row = F4 && (ty == 1 || ty == VT_R - 1);
+  // (row 1: j-2, row 7: j+1 -- wanted only where the row's own face is, cj <= nj)
+  const unsigned qej = (unsigned)(b.idx(ic, ty == 1 ? jc - 2 : min(jc + 1, b.nj + 1), 0) * 8);
   {
     double t4[4], t3[3], r, m;
     const unsigned qk = qc + (unsigned)kk * sk;
     ld_state(kk, t4, r, m);
-    PUT4(VS_S0, t4); PUT4(VS_SM, t4);
+    PUT4(VS_S0, t4);
+    if (!F4) PUT4(VS_SM, t4);
     sh[ty][l][VS_RHO] = r; sh[ty][l][VS_MU] = m;
     ld_state(kk + 1, t4, R1, MU1);
     PUT4(VS_SP, t4);
+    if (F4) {
+      ld_state(kk - 1, t4, RM, MUM);          // (k0 - 2 >= -2: the second ghost layer)
+      PUT4(VS_SM, t4);
+      ld_state(kk + 2, S2, R2, MU2);
+      WKM = b.ldb(PL_WID + 2, qk - sk);
+      WK2 = b.ldb(PL_WID + 2, qc + (unsigned)min(kk + 2, kcmax) * sk);
+    }
     ld_avec(0, qk, t3); PUT3(VS_AI0, t3);
     ld_avec(0, qk + sk, t3); PUT3(VS_AI1, t3);
     ld_avec(1, qk, t3); PUT3(VS_AJ0, t3);
@@ -261,9 +321,15 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
       const VtEdge jl{{VS_S0, td, l}, {VS_S0, td, ll}, {VS_AJ0, ty, l}, {VS_AJ0, ty, ll}};
       const VtEdge ku{meP, {VS_SP, ty, ll}, {VS_AK1, ty, l}, {VS_AK1, ty, ll}};
       const VtEdge kl{meM, {VS_SM, ty, ll}, {VS_AK0, ty, l}, {VS_AK0, ty, ll}};
-      vt_face(sh, g, VRef{VS_S0, ty, ll}, me0, VRef{VS_RHO, ty, ll}, meR, 0.0, 0.0, false,
-              nullptr, aF, aFm, AIp, ju, jl, ku, kl, sh[ty][ll][VS_VOL], sh[ty][l][VS_VOL],
-              sh[ty][ll][VS_WI], sh[ty][l][VS_WI], fi);
+      auto wide = [&](double* c0, double* c3, double& w0, double& w3) {
+        const int l0 = max(l - 2, 0);
+        vt_ld4(sh, VRef{VS_S0, ty, l0}, c0); vt_ld4(sh, VRef{VS_S0, ty, lr}, c3);
+        c0[4] = sh[ty][l0][VS_RHO]; c0[5] = sh[ty][l0][VS_MU]; w0 = sh[ty][l0][VS_WI];
+        c3[4] = sh[ty][lr][VS_RHO]; c3[5] = sh[ty][lr][VS_MU]; w3 = sh[ty][lr][VS_WI];
+      };
+      vt_face<F4>(sh, g, VRef{VS_S0, ty, ll}, me0, VRef{VS_RHO, ty, ll}, meR, 0.0, 0.0, false,
+                  nullptr, aF, aFm, AIp, ju, jl, ku, kl, sh[ty][ll][VS_VOL], sh[ty][l][VS_VOL],
+                  sh[ty][ll][VS_WI], sh[ty][l][VS_WI], fi, wide);
     }
     // hand the i-flux to the lane on the left, the j-flux to the row below as soon
     // as they exist: racc = +lower -upper (i) +lower (j)
@@ -280,9 +346,28 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
       const VtEdge il{{VS_S0, ty, ll}, {VS_S0, td, ll}, {VS_AI0, ty, l}, {VS_AI0, td, l}};
       const VtEdge ku{meP, {VS_SP, td, l}, {VS_AK1, ty, l}, {VS_AK1, td, l}};
       const VtEdge kl{meM, {VS_SM, td, l}, {VS_AK0, ty, l}, {VS_AK0, td, l}};
-      vt_face(sh, g, VRef{VS_S0, td, l}, me0, VRef{VS_RHO, td, l}, meR, 0.0, 0.0, false, nullptr,
-              aF, aFm, AJp, iu, il, ku, kl, sh[td][l][VS_VOL], sh[ty][l][VS_VOL],
-              sh[td][l][VS_WJ], sh[ty][l][VS_WJ], fj);
+      auto wide = [&](double* c0, double* c3, double& w0, double& w3) {
+        if (ty == 1) {                         // (wave-uniform: a row is a wave)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) c0[c] = EJ[c];
+          w0 = EJ[6];
+        } else {
+          const int t0 = max(ty - 2, 0);
+          vt_ld4(sh, VRef{VS_S0, t0, l}, c0);
+          c0[4] = sh[t0][l][VS_RHO]; c0[5] = sh[t0][l][VS_MU]; w0 = sh[t0][l][VS_WJ];
+        }
+        if (ty == VT_R - 1) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) c3[c] = EJ[c];
+          w3 = EJ[6];
+        } else {
+          vt_ld4(sh, VRef{VS_S0, tu, l}, c3);
+          c3[4] = sh[tu][l][VS_RHO]; c3[5] = sh[tu][l][VS_MU]; w3 = sh[tu][l][VS_WJ];
+        }
+      };
+      vt_face<F4>(sh, g, VRef{VS_S0, td, l}, me0, VRef{VS_RHO, td, l}, meR, 0.0, 0.0, false,
+                  nullptr, aF, aFm, AJp, iu, il, ku, kl, sh[td][l][VS_VOL], sh[ty][l][VS_VOL],
+                  sh[td][l][VS_WJ], sh[ty][l][VS_WJ], fj, wide);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) { sh[ty][l][VS_FJ + c] = fj[c]; racc[c] += fj[c]; }
@@ -297,8 +382,15 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
       const VtEdge il{{VS_SP, ty, ll}, {VS_S0, ty, ll}, {VS_AI1, ty, l}, {VS_AI0, ty, l}};
       const VtEdge ju{{VS_SP, tu, l}, {VS_S0, tu, l}, {VS_AJ1, tu, l}, {VS_AJ0, tu, l}};
       const VtEdge jl{{VS_SP, td, l}, {VS_S0, td, l}, {VS_AJ1, ty, l}, {VS_AJ0, ty, l}};
-      vt_face(sh, g, me0, meP, meR, meR, R1, MU1, true, SPr, aF, aFm, AK2, iu, il, ju, jl, V0, V1,
-              WK0, WK1, fk_up);
+      auto wide = [&](double* c0, double* c3, double& w0, double& w3) {
+        vt_ld4(sh, meM, c0);
+        c0[4] = RM; c0[5] = MUM; w0 = WKM;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) c3[c] = S2[c];
+        c3[4] = R2; c3[5] = MU2; w3 = WK2;
+      };
+      vt_face<F4>(sh, g, me0, meP, meR, meR, R1, MU1, true, SPr, aF, aFm, AK2, iu, il, ju, jl, V0,
+                  V1, WK0, WK1, fk_up, wide);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- request the plane that enters the window next step (after the faces:
@@ -307,13 +399,21 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
     double nS[4], nR, nMU, nAI[3], nAJ[3], nAK[3], nAIp[3] = {0, 0, 0}, nAJp[3] = {0, 0, 0};
     const unsigned qn = qc + (unsigned)(kk + 1) * sk;            // plane kk+1 (always valid)
     const unsigned qn2 = qc + (unsigned)min(kk + 2, kcmax) * sk; // cells of plane kk+2
-    ld_state(kk + 2, nS, nR, nMU);
+    ld_state(F4 ? kk + 3 : kk + 2, nS, nR, nMU);   // (F4: plane kk+2 is already in S2)
     ld_avec(0, qn2, nAI);
     ld_avec(1, qn2, nAJ);
     ld_avec(2, qc + (unsigned)min(kk + 3, kfmax) * sk, nAK);
     if (!VT_LDSAREA || l == VT_L - 1) ld_avec(0, qn + 8, nAIp);
     if (!VT_LDSAREA || ty == VT_R - 1) ld_avec(1, qn + sj, nAJp);
-    const double nV = b.ldb(PL_VOL, qn2), nWK = b.ldb(PL_WID + 2, qn2);
+    const double nV = b.ldb(PL_VOL, qn2);
+    const double nWK = b.ldb(PL_WID + 2, F4 ? qc + (unsigned)min(kk + 3, kcmax) * sk : qn2);
+    double nEJ[6] = {0, 0, 0, 0, 0, 0}, nEw = 0;
+    if (ej_row) {                              // the cell beyond the window's rows, plane kk+1
+      const unsigned qe = qej + (unsigned)(kk + 1) * sk;
+#pragma unroll
+      for (int e = 0; e < 5; ++e) nEJ[e] = b.ldb(b.st + e, qe);
+      nEw = b.ldb(PL_WID + 1, qe);
+    }
     const double nwi = b.ldb(PL_WID + 0, qn), nwj = b.ldb(PL_WID + 1, qn);
     __syncthreads();                           // all faces done: the windows may rotate
     if (own && !pre) {
@@ -354,15 +454,33 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
       double t3[3], t4[4];
       LD4(VS_S0, ty, l, t4); PUT4(VS_SM, t4);
       LD4(VS_SP, ty, l, t4); PUT4(VS_S0, t4);
-      PUT4(VS_SP, nS);
-      sh[ty][l][VS_RHO] = R1; R1 = nR;
-      sh[ty][l][VS_MU] = MU1; MU1 = nMU;
+      if (F4) {
+        PUT4(VS_SP, S2);
+        RM = sh[ty][l][VS_RHO]; MUM = sh[ty][l][VS_MU];
+        sh[ty][l][VS_RHO] = R1; R1 = R2; R2 = nR;
+        sh[ty][l][VS_MU] = MU1; MU1 = MU2; MU2 = nMU;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S2[c] = nS[c];
+        if (ej_row) {
+          const double rho = nEJ[0];
+          EJ[0] = nEJ[1]; EJ[1] = nEJ[2]; EJ[2] = nEJ[3];
+          EJ[3] = rho > 0.0 ? nEJ[4] * fast_rcp(rho * g.R) : 0.0;
+          EJ[4] = rho;
+          EJ[5] = rho > 0.0 ? viscosity(g, EJ[3]) : 0.0;
+          EJ[6] = nEw;
+        }
+      } else {
+        PUT4(VS_SP, nS);
+        sh[ty][l][VS_RHO] = R1; R1 = nR;
+        sh[ty][l][VS_MU] = MU1; MU1 = nMU;
+      }
       LD3(VS_AI1, ty, l, t3); PUT3(VS_AI0, t3); PUT3(VS_AI1, nAI);
       LD3(VS_AJ1, ty, l, t3); PUT3(VS_AJ0, t3); PUT3(VS_AJ1, nAJ);
       LD3(VS_AK1, ty, l, t3); PUT3(VS_AK0, t3); PUT3(VS_AK1, AK2);
       sh[ty][l][VS_VOL] = V1; V1 = nV;
       sh[ty][l][VS_WI] = nwi; sh[ty][l][VS_WJ] = nwj;
-      WK0 = WK1; WK1 = nWK;
+      if (F4) { WKM = WK0; WK0 = WK1; WK1 = WK2; WK2 = nWK; }
+      else { WK0 = WK1; WK1 = nWK; }
 #pragma unroll
       for (int c = 0; c < 4; ++c) fk_lo[c] = fk_up[c];
 #pragma unroll

@@ -142,6 +142,27 @@ def test_viscous_kernel_forms_agree(agx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [(70, 15, 9), (131, 20, 40)])
+def test_viscous_central_fourth_tile_agrees_with_gather(agx, n):
+    """viscousFaceReconstruction centralFourth on the LDS-staged kernel (60 x 6 owned cells
+    per workgroup: the four-cell face state takes two data lanes on the low side, the rows
+    beyond the window come from memory, plane k+2 of the own column is requested a step
+    early) against the one-thread-per-cell form; ragged tile edges in i and j, and with the
+    larger box workgroups that cross from one column tile into the next.  A reference length
+    of 20 um makes the box's Reynolds number a few hundred, so that the four-cell terms are
+    five orders above the rounding of the residual."""
+    wall = {3: ("viscousWall", 2), 1: ("characteristic", 1),
+            2: ("characteristic", 1), 4: ("characteristic", 1)}
+    case = synthetic.single_block_case(n=n, stretch=1.1, skew=0.01, bcs=wall,
+                                       equation_set="navierStokes",
+                                       viscous_face_reconstruction="centralFourth",
+                                       time_integration="rk4", cfl=0.3, l_ref=2.0e-5)
+    ref = _run_with_env(agx, case, 2, {"AGX_VISC": "gather"})
+    got = _run_with_env(agx, case, 2, {"AGX_VISC": "tile"})
+    assert rel_err(got, ref) < 1e-12
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sweeps", [1, 2])
 def test_lusgs_sweep_forms_agree(agx, sweeps):
     """The pipelined k-plane sweep on the diagonal-ordered arrays (default) and
