@@ -141,3 +141,61 @@ def test_two_ranks_on_one_gpu(oracle, kind, in_library):
     for r in range(2):
         assert rel_err(core(res[r][0]), core(ref.download("state", r))) < RTOL
     ref.close()
+
+
+def _rccl_worker(rank, port, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    import aither_amd
+    agx = aither_amd.load(5)
+    idbuf = ctypes.create_string_buffer(128)
+    if rank == 0:
+        agx.check(agx.rccl_unique_id(idbuf), "rccl_unique_id")
+    box = [idbuf.raw]
+    dist.broadcast_object_list(box, src=0)      # (the 128-byte id travels over gloo)
+    sol = Solver(agx, _case(kind, [0, 1]), device=rank, rank=rank, rccl=(box[0], 2, rank))
+    for nn in range(2):
+        sol.step(nn)
+    (gb,) = sol.block_ids
+    q.put((rank, sol.download("state", gb), np.array([h["l2"] ** 2 for h in sol.history])))
+    dist.barrier()
+    sol.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2,
+                    reason="the grouped ncclSend / ncclRecv need one GPU per rank")
+@pytest.mark.parametrize("kind", ["rk4", "lusgs"])
+def test_two_gpus_rccl_transport(oracle, kind):
+    """The built-in transport with a peer: one rank per GPU, slabs by grouped ncclSend /
+    ncclRecv on the library's stream, norm records by ncclAllGather (skipped on the one-GPU
+    boxes the suite normally runs on)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_rccl_worker, args=(r, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, st, l2 = q.get(timeout=300)
+        res[rank] = (st, l2)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    case = _case(kind, None)
+    ref = Solver(oracle, case)
+    for nn in range(2):
+        ref.step(nn)
+    ng = case.ng
+    core = lambda a: a[ng:-ng, ng:-ng, ng:-ng]
+    l2ref = np.array([h["l2"] ** 2 for h in ref.history])
+    assert rel_err(res[0][1], l2ref) < RTOL          # (global norms on every rank)
+    assert rel_err(res[1][1], l2ref) < RTOL
+    for r in range(2):
+        assert rel_err(core(res[r][0]), core(ref.download("state", r))) < RTOL
+    ref.close()
