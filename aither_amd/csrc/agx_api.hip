@@ -137,6 +137,11 @@ struct agx_ctx {
   bool use_tile = true;      // AGX_KERNEL=tile (default) | march
   int num_cu = 256;          // persistent workgroups of the tile kernel
   bool eager_ghosts = true;  // AGX_EAGER_GHOSTS=0: fill ghost cells at the start of agx_iterate
+  // AGX_OVERLAP=0: the slabs of x travel before a DPLUR sweep starts (default: while its
+  // interior cells are relaxed, on ov_stream)
+  bool overlap = true;
+  hipStream_t ov_stream = nullptr;
+  hipEvent_t ov_ready = nullptr, ov_done = nullptr;
   bool visc_gather = false;  // AGX_VISC=gather: one-thread-per-cell viscous kernel
   bool visc_march = false;   // AGX_VISC=march: face-once form without LDS staging
   int lusgs_mode = 1;        // AGX_LUSGS=plane (0: launch per hyperplane on the SoA
@@ -1153,6 +1158,7 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
       c->visc_march = !strcmp(w, "march");
     }
     if (const char* w = getenv("AGX_EAGER_GHOSTS")) c->eager_ghosts = atoi(w) != 0;
+    if (const char* w = getenv("AGX_OVERLAP")) c->overlap = atoi(w) != 0;
     if (const char* w = getenv("AGX_LUSGS")) c->lusgs_mode = !strcmp(w, "plane") ? 0 : 1;
     if (const char* w = getenv("AGX_SPIN_LIMIT")) c->spin_limit = std::max(1, atoi(w));
     if (const char* w = getenv("AGX_GRAPHS")) c->use_graphs = atoi(w) != 0;
@@ -1224,6 +1230,12 @@ void agx_ctx_destroy(agx_ctx* c) {
   if (c->nccl) ncclCommDestroy(c->nccl);
   for (auto& e : c->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+  if (c->ov_stream) {
+    hipStreamSynchronize(c->ov_stream);
+    hipStreamDestroy(c->ov_stream);
+    hipEventDestroy(c->ov_ready);
+    hipEventDestroy(c->ov_done);
+  }
   drop_sweep_graphs_all(c);
   if (c->blocks_tab) hipFree(c->blocks_tab);
   if (c->blocks_tab_host) hipHostFree(c->blocks_tab_host);
@@ -2424,7 +2436,7 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
       // (ImplicitLower/Upper only cross physical or connection faces).
       for (int e = 0; e < AGX_NEQ; ++e) std::swap(b.x[e], b.xold[e]);
       hipLaunchKernelGGL(k_dplur, cell_grid(b, CELL_BLOCK), CELL_BLOCK, 0,
-                         c->stream, b, c->gas, c->sp);
+                         c->stream, b, c->gas, c->sp, 0);
     }
   }
   if (!is_lusgs_solver(c)) c->halo_set[AGX_HALO_UPDATE] ^= 1;   // (x and xold changed roles)
@@ -2643,6 +2655,7 @@ int agx_rccl_exchange_create(agx_ctx* c, const void* id128, int nranks, int rank
   return 0;
 }
 
+static int halo_exchange_remote(agx_ctx* c, int what);
 // gridLevel::GetBoundaryConditions (state) / lusgs::Relax, dplur::Relax (update):
 // local connections, then the slabs of connections to other ranks
 int agx_halo_exchange(agx_ctx* c, int what) {
@@ -2651,6 +2664,12 @@ int agx_halo_exchange(agx_ctx* c, int what) {
   if (what >= AGX_HALO_VELGRAD_A && what <= AGX_HALO_VELGRAD_B && !(c->sp.implicit && c->sp.block))
     return fail("velocity gradients are kept (and exchanged) for the block-matrix solvers only");
   if (agx_halo_swap_local(c, what)) return 1;
+  return halo_exchange_remote(c, what);
+}
+
+// the slabs of connections to other ranks: pack, the transport's swap, unpack -- all on
+// c->stream (dplur_sweep_overlapped points it at its second stream meanwhile)
+static int halo_exchange_remote(agx_ctx* c, int what) {
   if (c->remote.empty()) return 0;
   if (!c->have_ex) return fail("connections to other ranks need an exchange (agx_set_exchange)");
   Timer t(c, G_BC);
@@ -2670,6 +2689,69 @@ int agx_halo_exchange(agx_ctx* c, int what) {
                             c->stream));
   for (auto& r : c->remote)
     if (agx_halo_unpack(c, r.cid, what, r.recv)) return 1;
+  return 0;
+}
+
+// One DPLUR / BDPLUR sweep of a rank with neighbours (dplur::Relax linearSolver.cpp:509-535:
+// SwapUpdate, then DPLUR on every block) with the interior / boundary split: point Jacobi
+// reads the previous x of a cell's six neighbours, so only the cells next to a block face with
+// a connection to another rank see a ghost cell that is still travelling.  All other cells are
+// relaxed on the context's stream while the slabs of the previous x are packed, swapped and
+// unpacked on a second stream; the cells of those faces follow when both are done.  Bitwise
+// the sequential form (the same cell function on two disjoint sets of cells).
+static bool overlap_applicable(const agx_ctx* c) {
+  return c->overlap && c->sp.implicit && !is_lusgs_solver(c) && c->have_ex && !c->remote.empty();
+}
+static int dplur_sweep_overlapped(agx_ctx* c) {
+  if (!c->ov_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->ov_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ov_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ov_done, hipEventDisableTiming));
+  }
+  // connections inside the rank first: their ghost cells are operands of the shell as well
+  if (agx_halo_swap_local(c, AGX_HALO_UPDATE)) return 1;
+  HIPCHK(hipEventRecord(c->ov_ready, c->stream));
+  x_changed(c);
+  std::vector<int> waits(c->blocks.size(), 0);     // faces with a connection to another rank
+  for (auto& r : c->remote) {
+    const Conn& k = c->conns[r.cid];
+    const int sd = my_side(c, k);
+    waits[k.c.local_block[sd]] |= 1 << (k.c.boundary[sd] - 1);
+  }
+  {
+    Timer t(c, G_SWEEP);
+    for (size_t n = 0; n < c->blocks.size(); ++n) {
+      BlockDev bs = c->blocks[n].d;      // x and xold in the roles they take in this sweep
+      for (int e = 0; e < AGX_NEQ; ++e) std::swap(bs.x[e], bs.xold[e]);
+      hipLaunchKernelGGL(k_dplur, cell_grid(bs, CELL_BLOCK), CELL_BLOCK, 0, c->stream, bs,
+                         c->gas, c->sp, waits[n]);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  {
+    struct OnStream {                    // pack / swap / unpack issue on c->stream
+      agx_ctx* c; hipStream_t keep;
+      OnStream(agx_ctx* c_, hipStream_t s) : c(c_), keep(c_->stream) { c->stream = s; }
+      ~OnStream() { c->stream = keep; }
+    } on(c, c->ov_stream);
+    HIPCHK(hipStreamWaitEvent(c->ov_stream, c->ov_ready, 0));
+    if (halo_exchange_remote(c, AGX_HALO_UPDATE)) return 1;
+    HIPCHK(hipEventRecord(c->ov_done, c->ov_stream));
+  }
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ov_done, 0));
+  {
+    Timer t(c, G_SWEEP);
+    for (size_t n = 0; n < c->blocks.size(); ++n) {
+      BlockDev& b = c->blocks[n].d;
+      for (int e = 0; e < AGX_NEQ; ++e) std::swap(b.x[e], b.xold[e]);
+      if (!waits[n]) continue;
+      const long nface = std::max({(long)b.ni * b.nj, (long)b.ni * b.nk, (long)b.nj * b.nk});
+      hipLaunchKernelGGL(k_dplur_shell, dim3((unsigned)((nface + 255) / 256), 6), dim3(256), 0,
+                         c->stream, b, c->gas, c->sp, waits[n]);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  c->halo_set[AGX_HALO_UPDATE] ^= 1;     // (x and xold changed roles)
   return 0;
 }
 
@@ -2774,6 +2856,12 @@ int agx_iterate(agx_ctx* c, int mm, double cfl, double* l2, agx_linf* linf,
     // dplur::Relax :509-535
     AGX_PHASE(agx_phase_implicit_begin(c));
     for (int s = 0; s < c->cfg.matrix_sweeps; ++s) {
+      if (!st && overlap_applicable(c)) {
+        // (the exchange is part of it: its failure ends the call like AGX_XCHG's)
+        const int r_ = dplur_sweep_overlapped(c);
+        if (r_) return r_;
+        continue;
+      }
       AGX_XCHG(AGX_HALO_UPDATE);
       AGX_PHASE(agx_phase_relax_forward(c, s));
       if (is_lusgs_solver(c)) {

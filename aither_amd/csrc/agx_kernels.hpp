@@ -3064,12 +3064,8 @@ k_lusgs_pipe(const BlockDev* tab, GasDev g, SolverDev sp, int full, PipeArgs pa)
 namespace agx {
 
 // dplur::DPLUR linearSolver.cpp:473-507 (point Jacobi on the copied xold)
-__global__ void __launch_bounds__(256)
-k_dplur(BlockDev b, GasDev g, SolverDev sp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  if (i >= b.ni || j >= b.nj) return;
+__device__ __forceinline__ void dplur_cell(const BlockDev& b, const GasDev& g,
+                                           const SolverDev& sp, int i, int j, int k) {
   const long q = b.idx(i, j, k);
   double acc[AGX_NEQ] = {0, 0, 0, 0, 0}, rb[AGX_NEQ];
   add_off_diag(b, g, sp, b.xold, i, j, k, q, true, 1.0, acc);
@@ -3083,6 +3079,44 @@ k_dplur(BlockDev b, GasDev g, SolverDev sp) {
     acc[e] = (b.mg_forcing ? rb[e] + b.mg_forcing[(long)e * b.nplane + q] : rb[e]) + acc[e];
   apply_ainv(b, sp, q, acc, out);
   store5(b.x, q, out);
+}
+// wait_mask (bit surface type - 1; 1, 2: i lower / upper, 3, 4: j, 5, 6: k): the block faces
+// whose ghost cells are still travelling -- connections to other ranks.  k_dplur leaves out the
+// cells next to them (0: every cell), k_dplur_shell relaxes those afterwards.
+__device__ __forceinline__ bool dplur_waits(const BlockDev& b, int m, int i, int j, int k) {
+  return ((m & 1) && i == 0) || ((m & 2) && i == b.ni - 1) || ((m & 4) && j == 0) ||
+         ((m & 8) && j == b.nj - 1) || ((m & 16) && k == 0) || ((m & 32) && k == b.nk - 1);
+}
+__global__ void __launch_bounds__(256)
+k_dplur(BlockDev b, GasDev g, SolverDev sp, int wait_mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= b.ni || j >= b.nj) return;
+  if (wait_mask && dplur_waits(b, wait_mask, i, j, k)) return;
+  dplur_cell(b, g, sp, i, j, k);
+}
+// blockIdx.y: surface type - 1; blockIdx.x * 256 + threadIdx.x: cell of that face (i fastest
+// where i runs).  A cell on several waiting faces belongs to the one with the highest type.
+__global__ void __launch_bounds__(256)
+k_dplur_shell(BlockDev b, GasDev g, SolverDev sp, int wait_mask) {
+  const int f = blockIdx.y;
+  if (!((wait_mask >> f) & 1)) return;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  int i, j, k;
+  if (f >= 4) {
+    if (t >= (long)b.ni * b.nj) return;
+    i = (int)(t % b.ni); j = (int)(t / b.ni); k = f == 5 ? b.nk - 1 : 0;
+  } else if (f >= 2) {
+    if (t >= (long)b.ni * b.nk) return;
+    i = (int)(t % b.ni); k = (int)(t / b.ni); j = f == 3 ? b.nj - 1 : 0;
+  } else {
+    if (t >= (long)b.nj * b.nk) return;
+    j = (int)(t % b.nj); k = (int)(t / b.nj); i = f == 1 ? b.ni - 1 : 0;
+  }
+  // (faces of a higher type that wait as well and hold this cell relax it)
+  if (dplur_waits(b, wait_mask & ~((2 << f) - 1), i, j, k)) return;
+  dplur_cell(b, g, sp, i, j, k);
 }
 
 // linearSolver::AXmB :58-90 / Residual :92-109 as a pure reduction

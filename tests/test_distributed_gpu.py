@@ -110,7 +110,7 @@ def test_rccl_transport_single_rank(agx, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,in_library", [(k, False) for k in sorted(KW)] +
-                         [("rk4", True), ("lusgs", True), ("rans", True),
+                         [("rk4", True), ("lusgs", True), ("dplur", True), ("rans", True),
                           ("wallLaw", False), ("wallLaw", True)])
 def test_two_ranks_on_one_gpu(oracle, kind, in_library):
     ctx = mp.get_context("spawn")
@@ -198,4 +198,73 @@ def test_two_gpus_rccl_transport(oracle, kind):
     assert rel_err(res[1][1], l2ref) < RTOL
     for r in range(2):
         assert rel_err(core(res[r][0]), core(ref.download("state", r))) < RTOL
+    ref.close()
+
+
+CUBE_KW = dict(inviscid_flux="ausm", limiter="none", time_integration="implicitEuler",
+               matrix_solver="dplur", matrix_sweeps=4, cfl=5.0)
+
+
+def _cube_worker(rank, port, overlap, solver, div, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["AGX_OVERLAP"] = overlap
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    import aither_amd
+    agx = aither_amd.load(5)
+    kw = dict(CUBE_KW, matrix_solver=solver)
+    case = synthetic.cube_blocks_case(n=(12, 10, 9), splits=(2, 2, 2),
+                                      ranks=[(b // div) % 2 for b in range(8)], **kw)
+    sol = Solver(agx, case, rank=rank, exchange=DistExchange(2))
+    for nn in range(2):
+        sol.step(nn)
+    q.put((rank, {gb: sol.download("state", gb) for gb in sol.block_ids},
+           np.array([h["l2"] ** 2 for h in sol.history])))
+    dist.barrier()
+    sol.close()
+    dist.destroy_process_group()
+
+
+def _cube_run(overlap, solver, div):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_cube_worker, args=(r, port, overlap, solver, div, q))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, st, l2 = q.get(timeout=300)
+        res[rank] = (st, l2)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,div", [("dplur", 1), ("dplur", 2), ("dplur", 4), ("bdplur", 1)])
+def test_dplur_interior_boundary_split(oracle, solver, div):
+    """A 2 x 2 x 2 cube of blocks, four per rank (connections inside a rank and across; div:
+    the ranks meet at i-, j- or k-faces): DPLUR / BDPLUR sweeps that relax the cells away from
+    the faces towards the other rank while the slabs of x travel on a second stream (default)
+    against the sequential form (AGX_OVERLAP=0) bit for bit, and against the single-process
+    oracle."""
+    split, seq = _cube_run("1", solver, div), _cube_run("0", solver, div)
+    kw = dict(CUBE_KW, matrix_solver=solver)
+    case = synthetic.cube_blocks_case(n=(12, 10, 9), splits=(2, 2, 2), **kw)
+    ref = Solver(oracle, case)
+    for nn in range(2):
+        ref.step(nn)
+    ng = case.ng
+    core = lambda a: a[ng:-ng, ng:-ng, ng:-ng]
+    l2ref = np.array([h["l2"] ** 2 for h in ref.history])
+    assert rel_err(split[0][1], l2ref) < RTOL
+    for r in range(2):
+        for gb, st in split[r][0].items():
+            assert np.array_equal(core(st), core(seq[r][0][gb]))
+            assert rel_err(core(st), core(ref.download("state", gb))) < RTOL
     ref.close()
