@@ -574,10 +574,17 @@ def main():
           and not args.dims):
         # the 8-block DPLUR case (BASELINE configs[3], strong scaling) the north-star
         # ">= 6x at 8 GPUs" clause is stated on rides in the same line
-        extra = ("dplur8", args, run_workload(args, "dplur8", api, world, rank, local_rank))
+        # (a failure of this second case must not cost the line its headline value)
+        try:
+            extra = ("dplur8", args, run_workload(args, "dplur8", api, world, rank, local_rank))
+        except (RuntimeError, SystemExit) as exc:
+            extra = ("dplur8", args, None, f"{type(exc).__name__}: {exc}")
+            print(f"[bench rank {rank}] extra.dplur8 failed: {exc}", file=sys.stderr, flush=True)
     if rank == 0:
         out = build_line(args, res, world)
-        if extra is not None:
+        if extra is not None and extra[2] is None:
+            out["extra"] = {extra[0]: {"error": extra[3]}}
+        elif extra is not None:
             e = build_line(extra[1], extra[2], world)
             out["extra"] = {extra[0]: {k: e[k] for k in (
                 "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
