@@ -181,8 +181,14 @@ struct agx_ctx {
   // launch pair per connection).  Legal when no slice reads a cell another connection's
   // insert writes (checked at agx_setup_finalize); tables per halo selector in device memory
   bool halo_batch = true;
+  bool halo_batch_required = false;
   int halo_batch_sides = 0;
   long halo_batch_nmax = 0;
+  // levels of the batched exchange (halo_batch_plan): the local connections in table order,
+  // and per level its first table entry, its entries and its longest side
+  std::vector<int> halo_conn_order;
+  struct HaloLevel { int first, sides; long nmax; };
+  std::vector<HaloLevel> halo_levels;
   // the state (fused explicit stages) and x (DPLUR) alternate between two sets of planes:
   // one table pair per set, built once each
   HaloSide* halo_tab_dev[5][2][2] = {};   // [what][plane set][gather | scatter]
@@ -1168,7 +1174,10 @@ int agx_ctx_create(int device, int rank, agx_ctx** out) {
     if (const char* w = getenv("AGX_SWEEP_RECORDS")) c->sweep_records = atoi(w) != 0;
     if (const char* w = getenv("AGX_MRESID_SPLIT")) c->mresid_split = std::min(64, std::max(1, atoi(w)));
     if (const char* w = getenv("AGX_MRESID")) c->mresid_march = strcmp(w, "plane") != 0;
-    if (const char* w = getenv("AGX_HALO_BATCH")) c->halo_batch = atoi(w) != 0;
+    if (const char* w = getenv("AGX_HALO_BATCH")) {   // 0: a launch pair per connection; require:
+      c->halo_batch = strcmp(w, "0") != 0;            // finalize fails where no batch forms
+      c->halo_batch_required = !strcmp(w, "require");
+    }
   }
   HIPCHK(hipMalloc((void**)&c->err_dev, sizeof(int)));
   HIPCHK(hipMemset(c->err_dev, 0, sizeof(int)));
@@ -1557,44 +1566,76 @@ long mresid_wgs(const agx_ctx* c, const BlockDev& b) {
 }
 
 namespace {
-// May all local connections be exchanged as "all slices, then all inserts"?  The reference
-// takes them one after the other (multiArray3d.hpp:790-828): a later slice would see an
-// earlier insert if it read a cell that insert writes.  Slices read physical cells except
-// where a patch borders another connection; checked here cell by cell.
+// The local connections exchanged in as few launches as their order allows.  The reference
+// takes them one after the other (multiArray3d.hpp:790-828: slice both sides, insert both):
+// where patches border other connections a later slice reads ghost cells an earlier insert
+// wrote, and two inserts write the same edge ghost cells.  Connections are therefore put
+// into levels -- "all slices of the level, then all its inserts", one gather and one scatter
+// launch per level -- such that a connection comes after (a higher level than) every earlier
+// one whose insert it reads or overwrites, and not before (the same level will do: slices
+// precede inserts) an earlier one whose slice reads what it inserts; checked cell by cell.
 int halo_batch_plan(agx_ctx* c, long* max_halo) {
   int sides = 0;
-  long total = 0, nmax = 0;
-  std::vector<std::vector<char>> is_dst(c->blocks.size());
-  for (auto& k : c->conns) {
-    const agx_connection& cc = k.c;
-    for (int s = 0; s < 2; ++s) {
-      if (cc.rank[s] != c->rank) continue;
-      auto& flags = is_dst[cc.local_block[s]];
-      if (flags.empty()) flags.assign((size_t)c->blocks[cc.local_block[s]].d.nplane, 0);
-      for (long q : k.side[s].h_dst) flags[(size_t)q] = 1;
-    }
-  }
-  bool ok = true;
-  for (auto& k : c->conns) {
+  long total = 0;
+  std::vector<std::vector<unsigned char>> wlev(c->blocks.size()), rlev(c->blocks.size());
+  auto flags = [&](std::vector<std::vector<unsigned char>>& v, int blk) -> std::vector<unsigned char>& {
+    if (v[blk].empty()) v[blk].assign((size_t)c->blocks[blk].d.nplane, 0);
+    return v[blk];
+  };
+  std::vector<std::pair<int, int>> order;        // (level, connection)
+  int nlev = 0;
+  for (size_t n = 0; n < c->conns.size(); ++n) {
+    auto& k = c->conns[n];
     const agx_connection& cc = k.c;
     if (!(cc.rank[0] == c->rank && cc.rank[1] == c->rank)) continue;
-    for (int s = 0; s < 2; ++s) {
-      const auto& flags = is_dst[cc.local_block[1 - s]];      // side s reads the partner block
-      for (long q : k.side[s].h_src) ok = ok && !flags[(size_t)q];
-      total += k.side[s].n;
-      nmax = std::max(nmax, k.side[s].n);
+    int lev = 1;
+    for (int sd = 0; sd < 2; ++sd) {
+      // side sd is filled from cells of the partner block
+      const auto& wr = flags(wlev, cc.local_block[1 - sd]);
+      for (long q : k.side[sd].h_src) lev = std::max(lev, wr[(size_t)q] + 1);
+      const auto& ww = flags(wlev, cc.local_block[sd]);
+      const auto& rr = flags(rlev, cc.local_block[sd]);
+      for (long q : k.side[sd].h_dst)
+        lev = std::max(lev, std::max<int>(ww[(size_t)q] + 1, rr[(size_t)q]));
     }
+    lev = std::min(lev, 250);
+    for (int sd = 0; sd < 2; ++sd) {
+      auto& rr = flags(rlev, cc.local_block[1 - sd]);
+      for (long q : k.side[sd].h_src) rr[(size_t)q] = std::max<unsigned char>(rr[(size_t)q], lev);
+      auto& ww = flags(wlev, cc.local_block[sd]);
+      for (long q : k.side[sd].h_dst) ww[(size_t)q] = (unsigned char)lev;
+      total += k.side[sd].n;
+    }
+    order.emplace_back(lev, (int)n);
+    nlev = std::max(nlev, lev);
     sides += 2;
   }
   for (auto& k : c->conns)
-    for (int s = 0; s < 2; ++s) {
-      std::vector<long>().swap(k.side[s].h_dst);
-      std::vector<long>().swap(k.side[s].h_src);
+    for (int sd = 0; sd < 2; ++sd) {
+      std::vector<long>().swap(k.side[sd].h_dst);
+      std::vector<long>().swap(k.side[sd].h_src);
     }
-  c->halo_batch = c->halo_batch && ok && sides >= 4;
+  // (250 levels: a chain this long gains nothing over the pairwise launches)
+  c->halo_batch = c->halo_batch && sides >= 4 && nlev < 250 && 2 * nlev < sides;
+  if (!c->halo_batch && c->halo_batch_required)
+    return fail("AGX_HALO_BATCH=require: %d local connections in %d levels", sides / 2, nlev);
   if (!c->halo_batch) return 0;
+  std::stable_sort(order.begin(), order.end(),
+                   [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
+  c->halo_conn_order.clear();
+  c->halo_levels.assign(nlev, agx_ctx::HaloLevel{0, 0, 0});
+  long nmax_all = 0;
+  for (auto& o : order) {
+    auto& L = c->halo_levels[o.first - 1];
+    if (L.sides == 0) L.first = 2 * (int)c->halo_conn_order.size();
+    L.sides += 2;
+    const auto& k = c->conns[o.second];
+    L.nmax = std::max(L.nmax, std::max(k.side[0].n, k.side[1].n));
+    nmax_all = std::max(nmax_all, L.nmax);
+    c->halo_conn_order.push_back(o.second);
+  }
   c->halo_batch_sides = sides;
-  c->halo_batch_nmax = nmax;
+  c->halo_batch_nmax = nmax_all;
   *max_halo = std::max(*max_halo, (total * AGX_NEQ + 1) / 2);     // (the buffer is 2 * max_halo)
   HIPCHK(hipHostMalloc((void**)&c->halo_tab_host, sizeof(HaloSide) * 2 * sides));
   return 0;
@@ -1613,9 +1654,9 @@ int halo_batch_tables(agx_ctx* c, int what) {
   HaloSide* p = c->halo_tab_host + sides;
   long off = 0;
   int n = 0;
-  for (auto& k : c->conns) {
+  for (int cid : c->halo_conn_order) {            // (level by level)
+    auto& k = c->conns[cid];
     const agx_connection& cc = k.c;
-    if (!(cc.rank[0] == c->rank && cc.rank[1] == c->rank)) continue;
     Block& b0 = c->blocks[cc.local_block[0]];
     Block& b1 = c->blocks[cc.local_block[1]];
     const bool z2 = halo_in_d2(b0, what);
@@ -2523,12 +2564,14 @@ int agx_halo_swap_local(agx_ctx* c, int what) {
   if (c->conns.empty()) return 0;
   Timer t(c, G_BC);
   if (c->halo_batch && c->halo_batch_sides > 0) {
-    // every slice, then every insert: one launch each (halo_batch_plan)
+    // level by level: every slice of the level, then every insert (halo_batch_plan)
     if (halo_batch_tables(c, what)) return 1;
-    const dim3 grid((unsigned)((c->halo_batch_nmax + 255) / 256), (unsigned)c->halo_batch_sides);
     HaloSide* const* tab = c->halo_tab_dev[what][c->halo_set[what]];
-    hipLaunchKernelGGL(k_halo_gather_all, grid, dim3(256), 0, c->stream, tab[0]);
-    hipLaunchKernelGGL(k_halo_scatter_all, grid, dim3(256), 0, c->stream, tab[1]);
+    for (const auto& L : c->halo_levels) {
+      const dim3 grid((unsigned)((L.nmax + 255) / 256), (unsigned)L.sides);
+      hipLaunchKernelGGL(k_halo_gather_all, grid, dim3(256), 0, c->stream, tab[0] + L.first);
+      hipLaunchKernelGGL(k_halo_scatter_all, grid, dim3(256), 0, c->stream, tab[1] + L.first);
+    }
     HIPCHK(hipGetLastError());
     return 0;
   }

@@ -252,8 +252,11 @@ def test_cube_of_blocks_dplur_parity(agx, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["dplur", "rk4", "lusgs"])
 def test_batched_local_halo_exchange_is_bitwise_the_sequential_one(agx, kind):
-    """All local connections exchanged in one gather + one scatter launch (default) against a
-    launch pair per connection (AGX_HALO_BATCH=0): 2 x 2 x 2 blocks, twelve connections; DPLUR
+    """The local connections exchanged level by level -- every slice of a level in one launch,
+    then every insert, a connection in a later level than the earlier ones whose inserts it
+    reads or overwrites (the cube's patches border each other: edge ghost cells travel on) --
+    against a launch pair per connection in the reference's order (AGX_HALO_BATCH=0; `require`
+    makes the set-up fail if no batch forms): 2 x 2 x 2 blocks, twelve connections; DPLUR
     (x and xold change roles every sweep), the fused RK4 stages (the two state buffers change
     roles every stage) and LU-SGS (x in the diagonal-ordered arrays)."""
     kw = {"dplur": dict(inviscid_flux="ausm", limiter="none", time_integration="implicitEuler",
@@ -263,7 +266,7 @@ def test_batched_local_halo_exchange_is_bitwise_the_sequential_one(agx, kind):
                         matrix_sweeps=2, cfl=5.0)}[kind]
     case = synthetic.cube_blocks_case(n=(9, 7, 6), splits=(2, 2, 2), **kw)
     out = {}
-    for mode in ("1", "0"):
+    for mode in ("require", "0"):
         old = os.environ.get("AGX_HALO_BATCH")
         os.environ["AGX_HALO_BATCH"] = mode
         try:
@@ -277,7 +280,7 @@ def test_batched_local_halo_exchange_is_bitwise_the_sequential_one(agx, kind):
             s.step(nn)
         out[mode] = [s.download("state", gb) for gb in range(8)]
         s.close()
-    for a, b in zip(out["1"], out["0"]):
+    for a, b in zip(out["require"], out["0"]):
         assert np.array_equal(a, b)
 
 
