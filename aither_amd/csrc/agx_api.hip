@@ -33,6 +33,15 @@ static int fail(const char* fmt, ...) {
       return fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
                   __FILE__, __LINE__);                                     \
   } while (0)
+// a kernel templated on the solver mode (solver_mode_of, agx_kernels.hpp)
+#define AGX_BY_MODE(sp, kernel, grid, block, stream, ...)                                  \
+  do {                                                                                     \
+    switch (agx::solver_mode_of(sp)) {                                                     \
+      case 0: hipLaunchKernelGGL(kernel<0>, grid, block, 0, stream, __VA_ARGS__); break;   \
+      case 1: hipLaunchKernelGGL(kernel<1>, grid, block, 0, stream, __VA_ARGS__); break;   \
+      default: hipLaunchKernelGGL(kernel<2>, grid, block, 0, stream, __VA_ARGS__); break;  \
+    }                                                                                      \
+  } while (0)
 
 namespace {
 
@@ -2476,8 +2485,8 @@ int agx_phase_relax_forward(agx_ctx* c, int sweep) {
       // the new x that nobody rewrites (physical boundaries) are never read
       // (ImplicitLower/Upper only cross physical or connection faces).
       for (int e = 0; e < AGX_NEQ; ++e) std::swap(b.x[e], b.xold[e]);
-      hipLaunchKernelGGL(k_dplur, cell_grid(b, CELL_BLOCK), CELL_BLOCK, 0,
-                         c->stream, b, c->gas, c->sp, 0);
+      AGX_BY_MODE(c->sp, k_dplur, cell_grid(b, CELL_BLOCK), CELL_BLOCK, c->stream, b, c->gas,
+                  c->sp, 0);
     }
   }
   if (!is_lusgs_solver(c)) c->halo_set[AGX_HALO_UPDATE] ^= 1;   // (x and xold changed roles)
@@ -2536,8 +2545,8 @@ int agx_phase_matrix_residual(agx_ctx* c, double* mr) {
       }
 #endif
       const dim3 grid = cell_grid(b, CELL_BLOCK);
-      hipLaunchKernelGGL(k_matrix_resid, grid, CELL_BLOCK, 0, c->stream, b,
-                         c->gas, c->sp, c->partials);
+      AGX_BY_MODE(c->sp, k_matrix_resid, grid, CELL_BLOCK, c->stream, b, c->gas, c->sp,
+                  c->partials);
       if (reduce_norms(c, n, (long)grid.x * grid.y * grid.z, out + n)) return 1;
     }
   }
@@ -2766,8 +2775,8 @@ static int dplur_sweep_overlapped(agx_ctx* c) {
     for (size_t n = 0; n < c->blocks.size(); ++n) {
       BlockDev bs = c->blocks[n].d;      // x and xold in the roles they take in this sweep
       for (int e = 0; e < AGX_NEQ; ++e) std::swap(bs.x[e], bs.xold[e]);
-      hipLaunchKernelGGL(k_dplur, cell_grid(bs, CELL_BLOCK), CELL_BLOCK, 0, c->stream, bs,
-                         c->gas, c->sp, waits[n]);
+      AGX_BY_MODE(c->sp, k_dplur, cell_grid(bs, CELL_BLOCK), CELL_BLOCK, c->stream, bs, c->gas,
+                  c->sp, waits[n]);
     }
     HIPCHK(hipGetLastError());
   }
@@ -2789,8 +2798,8 @@ static int dplur_sweep_overlapped(agx_ctx* c) {
       for (int e = 0; e < AGX_NEQ; ++e) std::swap(b.x[e], b.xold[e]);
       if (!waits[n]) continue;
       const long nface = std::max({(long)b.ni * b.nj, (long)b.ni * b.nk, (long)b.nj * b.nk});
-      hipLaunchKernelGGL(k_dplur_shell, dim3((unsigned)((nface + 255) / 256), 6), dim3(256), 0,
-                         c->stream, b, c->gas, c->sp, waits[n]);
+      AGX_BY_MODE(c->sp, k_dplur_shell, dim3((unsigned)((nface + 255) / 256), 6), dim3(256),
+                  c->stream, b, c->gas, c->sp, waits[n]);
     }
     HIPCHK(hipGetLastError());
   }

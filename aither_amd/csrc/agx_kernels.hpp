@@ -3063,6 +3063,18 @@ k_lusgs_pipe(const BlockDev* tab, GasDev g, SolverDev sp, int full, PipeArgs pa)
 #endif
 namespace agx {
 
+// MODE of the kernels below: the solver's run-time switches as compile-time constants for the
+// two common cases (0: scalar diagonal, inviscid, rusanov; 1: scalar, viscous, rusanov) --
+// the code of the other paths (block matrices, thin-shear-layer terms, approximateRoe) drops
+// out and with it most of the registers; 2: as configured.
+template <int MODE>
+__device__ __forceinline__ SolverDev solver_mode(SolverDev sp) {
+  if (MODE < 2) { sp.block = 0; sp.roe_jacobian = 0; sp.viscous = MODE; }
+  return sp;
+}
+inline int solver_mode_of(const SolverDev& sp) {
+  return (!sp.block && !sp.roe_jacobian) ? (sp.viscous ? 1 : 0) : 2;
+}
 // dplur::DPLUR linearSolver.cpp:473-507 (point Jacobi on the copied xold)
 __device__ __forceinline__ void dplur_cell(const BlockDev& b, const GasDev& g,
                                            const SolverDev& sp, int i, int j, int k) {
@@ -3087,8 +3099,10 @@ __device__ __forceinline__ bool dplur_waits(const BlockDev& b, int m, int i, int
   return ((m & 1) && i == 0) || ((m & 2) && i == b.ni - 1) || ((m & 4) && j == 0) ||
          ((m & 8) && j == b.nj - 1) || ((m & 16) && k == 0) || ((m & 32) && k == b.nk - 1);
 }
+template <int MODE>
 __global__ void __launch_bounds__(256)
-k_dplur(BlockDev b, GasDev g, SolverDev sp, int wait_mask) {
+k_dplur(BlockDev b, GasDev g, SolverDev sp_, int wait_mask) {
+  const SolverDev sp = solver_mode<MODE>(sp_);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
@@ -3098,8 +3112,10 @@ k_dplur(BlockDev b, GasDev g, SolverDev sp, int wait_mask) {
 }
 // blockIdx.y: surface type - 1; blockIdx.x * 256 + threadIdx.x: cell of that face (i fastest
 // where i runs).  A cell on several waiting faces belongs to the one with the highest type.
+template <int MODE>
 __global__ void __launch_bounds__(256)
-k_dplur_shell(BlockDev b, GasDev g, SolverDev sp, int wait_mask) {
+k_dplur_shell(BlockDev b, GasDev g, SolverDev sp_, int wait_mask) {
+  const SolverDev sp = solver_mode<MODE>(sp_);
   const int f = blockIdx.y;
   if (!((wait_mask >> f) & 1)) return;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -3120,8 +3136,10 @@ k_dplur_shell(BlockDev b, GasDev g, SolverDev sp, int wait_mask) {
 }
 
 // linearSolver::AXmB :58-90 / Residual :92-109 as a pure reduction
+template <int MODE>
 __global__ void __launch_bounds__(256)
-k_matrix_resid(BlockDev b, GasDev g, SolverDev sp, NormPartial* partials) {
+k_matrix_resid(BlockDev b, GasDev g, SolverDev sp_, NormPartial* partials) {
+  const SolverDev sp = solver_mode<MODE>(sp_);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
