@@ -2060,7 +2060,6 @@ static void d2_prepare(agx_ctx* c, Block& blk, int write_x, int again);
 #endif
 namespace {
 int mg_solver_ok(agx_ctx* c) {
-  if (AGX_NEQ != 5) return fail("multigrid: built for the 5-equation sets");
   if (!c->sp.implicit) return fail("multigrid: implicit time integration only");
   return 0;
 }
@@ -2222,6 +2221,11 @@ int agx_mg_reset_diagonal(agx_ctx* c) {
     HIPCHK(hipMemsetAsync(blk.d.a, 0, sizeof(double) * blk.d.nplane, c->stream));
     if (blk.d.am)
       HIPCHK(hipMemsetAsync(blk.d.am, 0, sizeof(double) * AGX_NJ * blk.d.nplane, c->stream));
+    if (AGX_NEQ > 5) {
+      HIPCHK(hipMemsetAsync(blk.d.a_t, 0, sizeof(double) * blk.d.nplane, c->stream));
+      if (blk.d.am_t)
+        HIPCHK(hipMemsetAsync(blk.d.am_t, 0, sizeof(double) * 2 * blk.d.nplane, c->stream));
+    }
   }
   return 0;
 }

@@ -273,8 +273,8 @@ k_block_diag_inv(BlockDev b, GasDev g, SolverDev sp) {
     *am = sp.diag_add ? *am + D[e] : D[e];       // (a coarse multigrid level, see SolverDev)
   }
   if (AGX_NEQ > 5) {       // the same number for k and omega (turbModel::InvJac)
-    b.am_t[q] = dt_;
-    b.am_t[b.nplane + q] = dt_;
+    b.am_t[q] = sp.diag_add ? b.am_t[q] + dt_ : dt_;
+    b.am_t[b.nplane + q] = sp.diag_add ? b.am_t[b.nplane + q] + dt_ : dt_;
   }
 }
 
@@ -322,7 +322,7 @@ k_inv_residual(BlockDev b, GasDev g, SolverDev sp, double cfl) {
   if (sp.implicit) b.a[q] = sp.diag_add ? b.a[q] + sr : sr;
   if (AGX_NEQ > 5) {
     b.specrad_t[q] = srt;
-    if (sp.implicit) b.a_t[q] = srt;
+    if (sp.implicit) b.a_t[q] = sp.diag_add ? b.a_t[q] + srt : srt;
   }
   if (!sp.viscous)
     b.dt[q] = sp.dt_fixed > 0.0 ? sp.dt_fixed : cfl * (b.vol[q] / fmax(sr, 0.0));
@@ -3240,10 +3240,13 @@ k_mg_axmb(BlockDev b, GasDev g, SolverDev sp) {
 #pragma unroll
     for (int e = 0; e < AGX_NJ; ++e) m[e] = b.am[(long)e * b.nplane + q];
     mat_vec5(m, xc, ax);
+#pragma unroll
+    for (int e = 5; e < AGX_NEQ; ++e) ax[e] = b.am_t[(long)(e - 5) * b.nplane + q] * xc[e];
   } else {
     const double a = b.d2.base ? b.ainv[q] : b.a[q];
+    const double at = AGX_NEQ > 5 ? b.a_t[q] : 0.0;
 #pragma unroll
-    for (int e = 0; e < AGX_NEQ; ++e) ax[e] = xc[e] * a;
+    for (int e = 0; e < AGX_NEQ; ++e) ax[e] = xc[e] * (e < 5 ? a : at);
   }
 #pragma unroll
   for (int e = 0; e < AGX_NEQ; ++e) {

@@ -350,8 +350,10 @@ int agx_nearest_wall_distance(agx_ctx *ctx, int64_t ncell, const double *cell_ce
  * fine context and the same block of the next coarser one, and give a level what
  * mgSolution::CycleAtLevel (mgSolution.cpp:160-205) needs beyond the phases above.  Both
  * contexts live on the same device.  The forcing term is carried by all four relaxations of
- * the 5-equation library (DPLUR, BDPLUR, BLU-SGS, scalar LU-SGS on its diagonal-ordered
- * production path and in its hyperplane form); the 7-equation library refuses these calls.  `to_coarse` [nk][nj][ni][3] (int32, host):
+ * both libraries (DPLUR, BDPLUR, BLU-SGS, scalar LU-SGS -- in the 5-equation library on its
+ * diagonal-ordered production path and in its hyperplane form); the turbulence equations of
+ * the 7-equation library are restricted, forced and prolonged like the flow equations, as
+ * the reference's transfers on varArray do.  `to_coarse` [nk][nj][ni][3] (int32, host):
  * the coarse cell (i, j, k) of every physical cell of the fine block. */
 enum { AGX_MG_STATE = 0, AGX_MG_UPDATE = 1, AGX_MG_FORCING = 2 };
 /* BlockRestriction (procBlock.hpp:636-690) of

@@ -3161,7 +3161,6 @@ int ora_mg_restrict(ora_ctx *f, ora_ctx *cz, int blk, int what, const int32_t *t
           for (int e = 0; e < NEQ; ++e)
             bc->state[NEQ * qc + e] = bc->state[NEQ * qc + e] + vf[p] * bf->state[NEQ * qf + e];
         }
-    if (NEQ > NF) return fail("mg_restrict: multigrid is built for the 5-equation sets");
     return 0;
   }
   if (what == AGX_MG_UPDATE) {

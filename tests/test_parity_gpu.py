@@ -1171,15 +1171,47 @@ def test_multigrid_other_solvers_parity(agx, oracle, solver, env):
 
 
 @pytest.mark.gpu
-def test_multigrid_is_refused_by_the_seven_equation_library(agx_rans):
-    """The multigrid calls are built for the 5-equation sets: the rans library refuses them
-    by name."""
+@pytest.mark.parametrize("solver,env", [("blusgs", {}), ("blusgs", {"AGX_SWEEP_PIPE": "0"}),
+                                        ("lusgs", {}), ("dplur", {}), ("bdplur", {})])
+def test_multigrid_seven_equations_parity(agx_rans, oracle, solver, env):
+    """k-omega SST 2003 under the cycle (the 7-equation library): the turbulence equations are
+    restricted, forced and prolonged with the flow equations, their part of the scalar and of
+    the block diagonal accumulates over the visits of a coarse level; V and W cycles on three
+    levels, two blocks with a connection, a viscous wall -- norms, matrix residual, state and
+    update of every level against the oracle."""
     from aither_amd.solver import MultigridSolver
-    cases, trs = synthetic.multigrid_levels(n=(12, 10, 8), levels=2, bcs=RANS_WALL,
-                                            equation_set="rans", turbulence_model="sst2003",
-                                            time_integration="implicitEuler",
-                                            matrix_solver="dplur", matrix_sweeps=2, cfl=10.0)
-    s = MultigridSolver(agx_rans, cases, trs)
-    with pytest.raises(RuntimeError, match="5-equation"):
-        s.step(0)
-    s.close()
+    kw = dict(n=(12, 10, 8), nblocks=2, axis="i", stretch=1.15, levels=3,
+              cycle="W" if solver == "blusgs" else "V", bcs=RANS_WALL, equation_set="rans",
+              turbulence_model="sst2003", time_integration="implicitEuler",
+              matrix_solver=solver, matrix_sweeps=2, cfl=10.0)
+    cg, tg = synthetic.multigrid_levels(**kw)
+    co, to = synthetic.multigrid_levels(**kw)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        sg = MultigridSolver(agx_rans, cg, tg)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    so = MultigridSolver(oracle, co, to)
+    g = cg[0].ng
+    for nn in range(3):
+        og, oo = sg.step(nn), so.step(nn)
+        assert np.allclose(og["l2"], oo["l2"], rtol=1e-9, atol=1e-12 * oo["l2"].max())
+        assert abs(og["matrix"] - oo["matrix"]) <= 1e-7 * oo["matrix"]
+        # (the saved update of a level may be round-off of the finest one's: measured against
+        # the largest update of the iteration)
+        scale = max(np.abs(so.download("update", gb, lev)).max()
+                    for lev in range(3) for gb in range(2))
+        for lev in range(3):
+            for gb in range(2):
+                a = sg.download("state", gb, lev)[g:-g, g:-g, g:-g]
+                b = so.download("state", gb, lev)[g:-g, g:-g, g:-g]
+                assert rel_err(a, b) < 1e-9, (nn, lev, gb, "state")
+                a = sg.download("update", gb, lev)[g:-g, g:-g, g:-g]
+                b = so.download("update", gb, lev)[g:-g, g:-g, g:-g]
+                assert np.abs(a - b).max() < 1e-9 * scale, (nn, lev, gb, "update")
+    sg.close(), so.close()
