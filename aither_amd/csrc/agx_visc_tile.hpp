@@ -239,10 +239,30 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
     s4[3] = rho > 0.0 ? b.ldb(b.st + 4, q) * fast_rcp(rho * g.R) : 0.0;
     mu = rho > 0.0 ? viscosity(g, s4[3]) : 0.0;
   };
+  // the same in two halves: the request (nothing computed on the values, so no wait is placed
+  // in front of the barrier that follows) and the conversion where the plane enters the window
+  auto rq_state = [&](int k, double* raw) {
+    const unsigned q = qc + (unsigned)min(k, kcmax) * sk;
+#pragma unroll
+    for (int e = 0; e < 5; ++e) raw[e] = b.ldb(b.st + e, q);
+  };
+  auto cv_state = [&](const double* raw, double* s4, double& rho, double& mu) {
+    rho = raw[0];
+    s4[0] = raw[1]; s4[1] = raw[2]; s4[2] = raw[3];
+    s4[3] = rho > 0.0 ? raw[4] * fast_rcp(rho * g.R) : 0.0;
+    mu = rho > 0.0 ? viscosity(g, s4[3]) : 0.0;
+  };
   auto ld_avec = [&](int d, unsigned q, double* a3) {
     const double mag = b.ldb(PL_FA + 4 * d + 3, q);
     a3[0] = b.ldb(PL_FA + 4 * d + 0, q) * mag; a3[1] = b.ldb(PL_FA + 4 * d + 1, q) * mag;
     a3[2] = b.ldb(PL_FA + 4 * d + 2, q) * mag;
+  };
+  auto rq_avec = [&](int d, unsigned q, double* raw) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) raw[c] = b.ldb(PL_FA + 4 * d + c, q);
+  };
+  auto cv_avec = [&](const double* raw, double* a3) {
+    a3[0] = raw[0] * raw[3]; a3[1] = raw[1] * raw[3]; a3[2] = raw[2] * raw[3];
   };
   auto PUT4 = [&](int var, const double* v) {
 #pragma unroll
@@ -393,18 +413,21 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
                   V1, WK0, WK1, fk_up, wide);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- request the plane that enters the window next step (after the faces:
-    // together with their operands it does not fit the register file; in flight
-    // during the barrier and the residual update) ----
-    double nS[4], nR, nMU, nAI[3], nAJ[3], nAK[3], nAIp[3] = {0, 0, 0}, nAJp[3] = {0, 0, 0};
+    // ---- request the plane that enters the window next step (after the faces; in flight
+    // during the barrier and the residual update).  RAW values: nothing is computed on them
+    // here -- with T, mu and the area vectors formed right behind the loads every wave waited
+    // for its requests in front of the barrier, a round trip to memory per step (R pass
+    // 5.45 -> 5.0 ms); they are converted where the plane enters the window.  Ahead of the
+    // faces the requests cost 60 registers and gain nothing (5.25 ms) ----
+    double nRaw[5], rAI[4], rAJ[4], rAK[4], rAIp[4] = {0, 0, 0, 0}, rAJp[4] = {0, 0, 0, 0};
     const unsigned qn = qc + (unsigned)(kk + 1) * sk;            // plane kk+1 (always valid)
     const unsigned qn2 = qc + (unsigned)min(kk + 2, kcmax) * sk; // cells of plane kk+2
-    ld_state(F4 ? kk + 3 : kk + 2, nS, nR, nMU);   // (F4: plane kk+2 is already in S2)
-    ld_avec(0, qn2, nAI);
-    ld_avec(1, qn2, nAJ);
-    ld_avec(2, qc + (unsigned)min(kk + 3, kfmax) * sk, nAK);
-    if (!VT_LDSAREA || l == VT_L - 1) ld_avec(0, qn + 8, nAIp);
-    if (!VT_LDSAREA || ty == VT_R - 1) ld_avec(1, qn + sj, nAJp);
+    rq_state(F4 ? kk + 3 : kk + 2, nRaw);          // (F4: plane kk+2 is already in S2)
+    rq_avec(0, qn2, rAI);
+    rq_avec(1, qn2, rAJ);
+    rq_avec(2, qc + (unsigned)min(kk + 3, kfmax) * sk, rAK);
+    if (!VT_LDSAREA || l == VT_L - 1) rq_avec(0, qn + 8, rAIp);
+    if (!VT_LDSAREA || ty == VT_R - 1) rq_avec(1, qn + sj, rAJp);
     const double nV = b.ldb(PL_VOL, qn2);
     const double nWK = b.ldb(PL_WID + 2, F4 ? qc + (unsigned)min(kk + 3, kcmax) * sk : qn2);
     double nEJ[6] = {0, 0, 0, 0, 0, 0}, nEw = 0;
@@ -452,6 +475,10 @@ k_visc_tile(SlabDev b, GasDev g, SolverDev sp, double cfl, int gx, int gy) {
     // ---- rotate the window in the own LDS slots ----
     {
       double t3[3], t4[4];
+      double nS[4], nR, nMU, nAI[3], nAJ[3], nAK[3], nAIp[3], nAJp[3];
+      cv_state(nRaw, nS, nR, nMU);
+      cv_avec(rAI, nAI); cv_avec(rAJ, nAJ); cv_avec(rAK, nAK);
+      cv_avec(rAIp, nAIp); cv_avec(rAJp, nAJp);
       LD4(VS_S0, ty, l, t4); PUT4(VS_SM, t4);
       LD4(VS_SP, ty, l, t4); PUT4(VS_S0, t4);
       if (F4) {
